@@ -1,0 +1,224 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE: ctypes loader for the CPU oracle.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (sdf_playground_amd) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OrcFrame(ctypes.Structure):
+    """Mirror of `struct orc_frame` (oracle/oracle_api.cpp)."""
+
+    _fields_ = [
+        ("eye", ctypes.c_float * 3),
+        ("front", ctypes.c_float * 3),
+        ("right", ctypes.c_float * 3),
+        ("top", ctypes.c_float * 3),
+        ("stime", ctypes.c_float),
+        ("width", ctypes.c_int),
+        ("height", ctypes.c_int),
+        ("iter_count", ctypes.c_int),
+        ("bounce_count", ctypes.c_int),
+        ("ray_count", ctypes.c_int),
+        ("light_count", ctypes.c_int),
+        ("range", ctypes.c_float),
+        ("max_cost_default", ctypes.c_int),
+        ("debug_nx", ctypes.c_float),
+        ("debug_ny", ctypes.c_float),
+        ("debug_nz", ctypes.c_float),
+        ("debug_scale", ctypes.c_float),
+        ("debug_x", ctypes.c_float),
+        ("debug_y", ctypes.c_float),
+        ("debug_z", ctypes.c_float),
+        ("show_objects", ctypes.c_float),
+        ("scene_var", ctypes.c_float * 8),
+    ]
+
+
+def build(census=False, ref=True):
+    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
+    targets = ["liboracle.so"]
+    if census:
+        targets.append("liboracle_census.so")
+    if ref:
+        targets.append("ref")
+    subprocess.run(["make", "-s", "-C", _HERE] + targets, check=True)
+
+
+_libs = {}
+
+
+def lib(census=False):
+    name = "liboracle_census.so" if census else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build(census=census, ref=False)
+        L = ctypes.CDLL(path)
+        L.orc_scene_name.restype = ctypes.c_char_p
+        L.orc_render.argtypes = [
+            ctypes.c_char_p, ctypes.POINTER(OrcFrame), ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+            ctypes.c_void_p,
+        ]
+        L.orc_camera_lookat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+        L.orc_camera_direction.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+        L.orc_kat.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        _libs[name] = L
+    return _libs[name]
+
+
+def ref_camera_lib():
+    """oracle/_ref/libref_camera.so (the reference's own Camera.cpp/Math3D.cpp), or None."""
+    path = os.path.join(_HERE, "_ref", "libref_camera.so")
+    if not os.path.exists(path):
+        return None
+    L = ctypes.CDLL(path)
+    L.ref_camera_basis.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    return L
+
+
+def scene_names():
+    L = lib()
+    return [L.orc_scene_name(i).decode() for i in range(L.orc_scene_count())]
+
+
+def var_table(scene):
+    """[(name, min, max, start, step, value, scene_slot)] in std::map order."""
+    buf = ctypes.create_string_buffer(8192)
+    n = lib().orc_var_table(scene.encode(), buf, len(buf))
+    if n < 0:
+        raise ValueError("unknown scene %r" % scene)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        p = line.split()
+        rows.append((p[0],) + tuple(float(x) for x in p[1:6]) + (int(p[6]),))
+    return rows
+
+
+def parse_vars(text):
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib().orc_parse_vars(text.encode(), buf, len(buf))
+    if n < 0:
+        raise ValueError("parse error")
+    rows = {}
+    for line in buf.value.decode().splitlines():
+        p = line.split()
+        rows[p[0]] = tuple(float(x) for x in p[1:6])
+    return rows
+
+
+def split_string(s, start, end=""):
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib().orc_split_string(s.encode(), start.encode(), end.encode(), buf, len(buf))
+    assert n >= 0
+    raw = buf.raw[:n].decode()
+    parts, seps = raw.split("\x1e")
+    return parts.split("\x1f"), (seps.split("\x1f") if seps else [])
+
+
+def remove_spaces(s):
+    buf = ctypes.create_string_buffer(1 << 12)
+    lib().orc_remove_spaces(s.encode(), buf, len(buf))
+    return buf.value.decode()
+
+
+def camera_lookat(eye, lookat, fovy, aspect, roll=0.0):
+    e = np.asarray(eye, np.float32)
+    t = np.asarray(lookat, np.float32)
+    out = np.zeros(12, np.float32)
+    lib().orc_camera_lookat(e.ctypes.data, t.ctypes.data, fovy, aspect, roll, out.ctypes.data)
+    return out.reshape(4, 3)
+
+
+def camera_direction(eye, direction, fovy, aspect, roll=0.0):
+    e = np.asarray(eye, np.float32)
+    t = np.asarray(direction, np.float32)
+    out = np.zeros(12, np.float32)
+    lib().orc_camera_direction(e.ctypes.data, t.ctypes.data, fovy, aspect, roll, out.ctypes.data)
+    return out.reshape(4, 3)
+
+
+def default_frame(scene, width, height, basis=None, stime=0.0):
+    """Reference defaults (pshader_sdf.hlsl:60-64,350; F10 variable defaults)."""
+    f = OrcFrame()
+    if basis is None:
+        # start-up camera, Application.cpp:214-224
+        basis = camera_lookat((0.0, 2.0, -3.0), (0.0, 1.0, 0.0), np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0), np.float32(width) / np.float32(height))
+    for i in range(3):
+        f.eye[i], f.front[i], f.right[i], f.top[i] = basis[0][i], basis[1][i], basis[2][i], basis[3][i]
+    f.stime = stime
+    f.width, f.height = width, height
+    f.iter_count, f.bounce_count, f.ray_count, f.light_count = 100, 16, 8, 8
+    f.range = 100.0
+    f.max_cost_default = 7
+    for name, _mn, _mx, start, _st, _v, slot in var_table(scene):
+        if slot >= 0:
+            f.scene_var[slot] = start
+        else:
+            setattr(f, name, start)
+    return f
+
+
+def render(scene, frame, region=None, step=(1, 1), nthreads=None, stats=False, census=False, out=None):
+    """Returns (rgba[H,W,4] float32, stats[H,W,3] uint32 or None, totals[4] uint64)."""
+    W, H = frame.width, frame.height
+    if out is None:
+        out = np.zeros((H, W, 4), np.float32)
+    st = np.zeros((H, W, 3), np.uint32) if stats else None
+    x0, y0, x1, y1 = region if region else (0, 0, W, H)
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    totals = np.zeros(4, np.uint64)
+    rc = lib(census).orc_render(scene.encode(), ctypes.byref(frame), out.ctypes.data, st.ctypes.data if stats else None,
+                                x0, y0, x1, y1, step[0], step[1], nthreads, totals.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_render failed: %d" % rc)
+    return out, st, totals
+
+
+def kat(fn, *args, nout=4):
+    a = np.zeros(16, np.float32)
+    flat = np.asarray(args, np.float32).ravel()
+    a[: len(flat)] = flat
+    o = np.zeros(8, np.float32)
+    n = lib().orc_kat(fn.encode(), a.ctypes.data, o.ctypes.data)
+    if n < 0:
+        raise KeyError(fn)
+    return o[:n].copy()
+
+
+def kat_u32(fn, u):
+    a = np.zeros(16, np.float32)
+    a.view(np.uint32)[0] = u
+    o = np.zeros(8, np.float32)
+    n = lib().orc_kat(fn.encode(), a.ctypes.data, o.ctypes.data)
+    assert n == 1
+    return o
+
+
+def tonemap_png(rgba, path):
+    """Quick-look image: the reference's tone map without bloom (pshader_hdr.hlsl:20-25)."""
+    import struct
+    import zlib
+
+    rgb = rgba[..., :3].astype(np.float64)
+    a = rgba[..., 3:4].astype(np.float64)
+    ldr = 1.0 - np.exp(-rgb)
+    img = rgb + a * (ldr - rgb)
+    img8 = (np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)
+    H, W, _ = img8.shape
+    raw = b"".join(b"\x00" + img8[y].tobytes() for y in range(H))
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
