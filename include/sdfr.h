@@ -1,0 +1,145 @@
+/* sdfr.h -- C ABI of the MI355X-native SDF raymarch renderer (libsdfr.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Gotbread/sdf-playground: the SDF render
+ * stage `class SDFRenderer` (Engine/SDFRenderer.h:17-44), i.e. the per-pixel raymarch loop
+ * of Engine/shader/pshader_sdf.hlsl.  Each entry point names the reference interface it
+ * replaces.  Plain C types only; no torch, no C++ types.
+ *
+ * Conventions
+ *   - every call returns an sdfr_status (0 = ok, < 0 = error); sdfr_last_error() gives text.
+ *     The reference returns bool and pops a MessageBox (Util.cpp:61-69); nothing here aborts.
+ *   - a handle is bound to one GPU and one HIP stream; calls on one handle are not
+ *     thread-safe (the reference is single-threaded, Application.cpp:65-95).
+ *   - sdfr_render* enqueue work on the handle's stream and return; sdfr_sync waits.
+ *   - images are row-major, row 0 = top row, 4 channels interleaved; alpha is the
+ *     tone-mapping flag in {0, 1} (pshader_sdf.hlsl:636-638), not coverage.
+ */
+#ifndef SDFR_H
+#define SDFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfr_renderer sdfr_renderer;
+
+typedef enum sdfr_status
+{
+	SDFR_OK = 0,
+	SDFR_ERR_INVALID_ARGUMENT = -1,
+	SDFR_ERR_UNKNOWN_SCENE = -2,
+	SDFR_ERR_UNKNOWN_VARIABLE = -3, /* value ignored, like ShaderVariableManager::setValue (ShaderUtil.cpp:234-240) */
+	SDFR_ERR_NO_SCENE = -4,         /* render without a loaded scene: SDFRenderer::render returns false (SDFRenderer.cpp:70-73) */
+	SDFR_ERR_HIP = -5,
+	SDFR_ERR_NO_DEVICE = -6
+} sdfr_status;
+
+/* ---- lifetime: SDFRenderer::init(Graphics&) (SDFRenderer.cpp:9-25) ----------------------- */
+int sdfr_create(int device_ordinal, sdfr_renderer **out);
+void sdfr_destroy(sdfr_renderer *r);
+const char *sdfr_last_error(const sdfr_renderer *r);
+/* work is enqueued on this hipStream_t (NULL = the default stream) */
+int sdfr_set_stream(sdfr_renderer *r, void *hip_stream);
+
+/* ---- scene selection: SceneManager list (SceneManager.cpp:142-158) + Application::loadScene
+ *      (Application.cpp:318-322) + SDFRenderer::initShader (SDFRenderer.cpp:27-53).
+ *      Names are the reference's file stems without "sdf_scene_". ------------------------------ */
+int sdfr_scene_count(void);
+const char *sdfr_scene_name(int index);
+int sdfr_load_scene(sdfr_renderer *r, const char *name);
+const char *sdfr_current_scene(const sdfr_renderer *r);
+
+/* ---- parameter surface 1: shader variables = SDFRenderer::getVariableMap()
+ *      (ShaderVariable.h:6-12; ShaderUtil.cpp:122-267).  Index order = std::map order
+ *      (lexicographic by name), which is also the reference's constant-buffer order. --------- */
+typedef struct sdfr_variable
+{
+	char name[48];
+	float minval, maxval, start, step;
+	float value;
+} sdfr_variable;
+int sdfr_var_count(const sdfr_renderer *r);
+int sdfr_var_info(const sdfr_renderer *r, int index, sdfr_variable *out);
+int sdfr_var_set(sdfr_renderer *r, const char *name, float value);
+int sdfr_var_get(const sdfr_renderer *r, const char *name, float *out);
+int sdfr_vars_reset(sdfr_renderer *r); /* VariableManager::resetVariables: value = start */
+
+/* ---- parameter surface 2: camera + time = the camera constant buffer b0
+ *      (SDFRenderer.h:29-34, SDFRenderer.cpp:85-95) and SDFRenderer::setParameters(stime). ---- */
+int sdfr_set_camera(sdfr_renderer *r, const float eye[3], const float front[3], const float right[3], const float top[3]);
+/* FPS-mode Camera of the reference (Camera.cpp:24-49,156-166): basis from eye -> lookat */
+int sdfr_set_camera_lookat(sdfr_renderer *r, const float eye[3], const float lookat[3], float fovy, float aspect, float roll);
+int sdfr_set_camera_direction(sdfr_renderer *r, const float eye[3], const float direction[3], float fovy, float aspect, float roll);
+int sdfr_get_camera(const sdfr_renderer *r, float out_eye_front_right_top[12]);
+int sdfr_set_time(sdfr_renderer *r, float stime);
+
+/* ---- parameter surface 3: the driver's compile-time limits (pshader_sdf.hlsl:60-64,350)
+ *      as run-time values.  Defaults = reference; anything else is a labelled extension. ------ */
+typedef struct sdfr_limits
+{
+	int iter_count;       /* ITER_COUNT   100, >= 1 */
+	int bounce_count;     /* BOUNCE_COUNT 16, 0..16 */
+	int ray_count;        /* RAY_COUNT    8, 1..8 */
+	int light_count;      /* LIGHT_COUNT  8, 0..8 */
+	float range;          /* RANGE        100 */
+	int max_cost_default; /* MaterialOutput.max_cost 7, 0..250 */
+} sdfr_limits;
+int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out);
+int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *limits);
+
+/* how the pipeline stages are scheduled on the GPU (results are identical) */
+typedef enum sdfr_schedule
+{
+	SDFR_SCHEDULE_WAVEFRONT = 0, /* rays in HBM, persistent march waves refilled by ballot, separate shade kernel */
+	SDFR_SCHEDULE_PIXEL = 1      /* one lane per pixel, start to finish */
+} sdfr_schedule;
+int sdfr_set_schedule(sdfr_renderer *r, int schedule);
+/* per-round HIP events around the march and shade kernels (sdfr_stats.ms_march / ms_shade); off by default */
+int sdfr_set_profiling(sdfr_renderer *r, int enabled);
+
+/* ---- output: the HDR render target SDFRenderer::render draws into
+ *      (Application.cpp:274-284; R16G16B16A16_FLOAT, Postprocessing.cpp:23). ------------------ */
+typedef enum sdfr_format
+{
+	SDFR_RGBA32F = 0, /* what the shader computes */
+	SDFR_RGBA16F = 1  /* what the reference's render target stores */
+} sdfr_format;
+
+/* Render a width x height frame into `out` (device pointer if out_on_host == 0, else host).
+ * pixel_stats (optional, same memory space as `out`): 3 uint32 per pixel = {rays, march
+ * evaluations, hits}.  Replaces SDFRenderer::render (SDFRenderer.cpp:65-107). */
+int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats);
+
+/* Multi-GPU: the frame is cut into strips of SDFR_STRIP_ROWS rows; strip s belongs to rank
+ * s % world.  sdfr_render_strips renders this rank's strips into a compact buffer
+ * (sdfr_strip_buffer_pixels pixels, strips in increasing order); sdfr_assemble_strips, on the
+ * root, scatters a gathered [world][strip_buffer_pixels] array into the full image.  The
+ * reference is single-GPU; this is the sharding of SURVEY.md 8(e). */
+#define SDFR_STRIP_ROWS 8
+int64_t sdfr_strip_buffer_pixels(int width, int height, int world);
+int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format);
+int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format);
+
+int sdfr_sync(sdfr_renderer *r);
+
+/* ---- observability: GPUProfiler::profile("setup"/"draw") (SDFRenderer.cpp:100,104) ---------- */
+typedef struct sdfr_stats
+{
+	double ms_gpu;          /* HIP-event time of the last render on the handle's stream */
+	double ms_march;        /* wavefront schedule: time inside the march kernels */
+	double ms_shade;        /* wavefront schedule: time inside the shade kernels */
+	uint64_t pixels;
+	uint64_t rays;          /* bounce-loop iterations = primary + secondary rays */
+	uint64_t march_evals;   /* scene-distance evaluations made while marching */
+	uint64_t hits;
+	uint32_t march_launches, shade_launches;
+} sdfr_stats;
+/* waits for the last render, then reports it */
+int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFR_H */

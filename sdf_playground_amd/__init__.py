@@ -1,0 +1,380 @@
+"""sdf_playground_amd -- MI355X-native SDF raymarch renderer (hot path of Gotbread/sdf-playground).
+
+Python host side above the C ABI (include/sdfr.h, libsdfr.so).  The classes mirror the
+reference's host interface for this path so that code written against the reference reads
+the same here:
+
+    SDFRenderer   Engine/SDFRenderer.h:17-44   init / initShader / setParameters /
+                                               getVariableMap / render
+    Camera        Engine/Camera.h:5-64         SetEye / SetLookat / SetDirection / SetAspect /
+                                               SetFOVY / SetRoll  (FPS mode)
+    Variable      Engine/ShaderVariable.h:6-12 minval / maxval / start / step / value
+
+All pixels come from the HIP kernels; if libsdfr.so cannot be loaded or no GPU is present
+the calls raise -- there is no CPU fallback.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfr.so")
+
+SDFR_OK = 0
+SCHEDULE_WAVEFRONT = 0
+SCHEDULE_PIXEL = 1
+RGBA32F = 0
+RGBA16F = 1
+STRIP_ROWS = 8
+
+_STATUS = {
+    0: "SDFR_OK", -1: "SDFR_ERR_INVALID_ARGUMENT", -2: "SDFR_ERR_UNKNOWN_SCENE", -3: "SDFR_ERR_UNKNOWN_VARIABLE",
+    -4: "SDFR_ERR_NO_SCENE", -5: "SDFR_ERR_HIP", -6: "SDFR_ERR_NO_DEVICE",
+}
+
+
+class SdfrError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (_STATUS.get(code, str(code)), message))
+        self.code = code
+
+
+class _CVariable(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("minval", ctypes.c_float), ("maxval", ctypes.c_float), ("start", ctypes.c_float),
+                ("step", ctypes.c_float), ("value", ctypes.c_float)]
+
+
+class Limits(ctypes.Structure):
+    """sdfr_limits: the driver's compile-time limits (pshader_sdf.hlsl:60-64,350) at run time."""
+
+    _fields_ = [("iter_count", ctypes.c_int), ("bounce_count", ctypes.c_int), ("ray_count", ctypes.c_int), ("light_count", ctypes.c_int),
+                ("range", ctypes.c_float), ("max_cost_default", ctypes.c_int)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("ms_gpu", ctypes.c_double), ("ms_march", ctypes.c_double), ("ms_shade", ctypes.c_double), ("pixels", ctypes.c_uint64),
+                ("rays", ctypes.c_uint64), ("march_evals", ctypes.c_uint64), ("hits", ctypes.c_uint64), ("march_launches", ctypes.c_uint32),
+                ("shade_launches", ctypes.c_uint32)]
+
+
+# every symbol include/sdfr.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "sdfr_create", "sdfr_destroy", "sdfr_last_error", "sdfr_set_stream", "sdfr_scene_count", "sdfr_scene_name", "sdfr_load_scene",
+    "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
+    "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
+    "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
+    "sdfr_sync", "sdfr_get_stats",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 into libsdfr.so (in-tree)."""
+    from . import buildlib as _build
+
+    return _build.build(force=force)
+
+
+def load_library():
+    """dlopen libsdfr.so.  torch (when installed) is imported first so that both share one
+    HIP runtime (same SONAME, libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdfrError(-5, "libsdfr.so is not built: run `python -m sdf_playground_amd.buildlib` (needs hipcc)")
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.sdfr_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.sdfr_destroy.argtypes = [vp]
+    L.sdfr_destroy.restype = None
+    L.sdfr_last_error.argtypes = [vp]
+    L.sdfr_last_error.restype = ctypes.c_char_p
+    L.sdfr_set_stream.argtypes = [vp, vp]
+    L.sdfr_scene_name.argtypes = [ci]
+    L.sdfr_scene_name.restype = ctypes.c_char_p
+    L.sdfr_load_scene.argtypes = [vp, ctypes.c_char_p]
+    L.sdfr_current_scene.argtypes = [vp]
+    L.sdfr_current_scene.restype = ctypes.c_char_p
+    L.sdfr_var_count.argtypes = [vp]
+    L.sdfr_var_info.argtypes = [vp, ci, ctypes.POINTER(_CVariable)]
+    L.sdfr_var_set.argtypes = [vp, ctypes.c_char_p, cf]
+    L.sdfr_var_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(cf)]
+    L.sdfr_vars_reset.argtypes = [vp]
+    f3 = ctypes.POINTER(cf)
+    L.sdfr_set_camera.argtypes = [vp, f3, f3, f3, f3]
+    L.sdfr_set_camera_lookat.argtypes = [vp, f3, f3, cf, cf, cf]
+    L.sdfr_set_camera_direction.argtypes = [vp, f3, f3, cf, cf, cf]
+    L.sdfr_get_camera.argtypes = [vp, f3]
+    L.sdfr_set_time.argtypes = [vp, cf]
+    L.sdfr_get_limits.argtypes = [vp, ctypes.POINTER(Limits)]
+    L.sdfr_set_limits.argtypes = [vp, ctypes.POINTER(Limits)]
+    L.sdfr_set_schedule.argtypes = [vp, ci]
+    L.sdfr_set_profiling.argtypes = [vp, ci]
+    L.sdfr_strip_buffer_pixels.argtypes = [ci, ci, ci]
+    L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
+    L.sdfr_render.argtypes = [vp, ci, ci, vp, ci, ci, vp]
+    L.sdfr_render_strips.argtypes = [vp, ci, ci, ci, ci, vp, ci]
+    L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
+    L.sdfr_sync.argtypes = [vp]
+    L.sdfr_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def scene_names():
+    L = load_library()
+    return [L.sdfr_scene_name(i).decode() for i in range(L.sdfr_scene_count())]
+
+
+def strip_buffer_pixels(width, height, world):
+    return int(load_library().sdfr_strip_buffer_pixels(width, height, world))
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def to_radian(deg):
+    """Math3D::ToRadian (Math3D.h:299-303) in fp32."""
+    return float(np.float32(deg) * np.float32(3.14159265358979) / np.float32(180.0))
+
+
+class Camera:
+    """First-person camera of the reference (Engine/Camera.h), parameters only: the basis
+    arithmetic runs in the C++ host library (sdfr_set_camera_lookat / _direction)."""
+
+    def __init__(self):
+        # Application.cpp:214-224
+        self.eye = (0.0, 2.0, -3.0)
+        self.target = (0.0, 1.0, 0.0)
+        self.target_is_direction = False
+        self.fovy = to_radian(60.0)
+        self.aspect = float(np.float32(1200.0) / np.float32(800.0))
+        self.roll = 0.0
+
+    def SetEye(self, eye):
+        self.eye = tuple(float(x) for x in eye)
+
+    def SetLookat(self, lookat):
+        self.target = tuple(float(x) for x in lookat)
+        self.target_is_direction = False
+
+    def SetDirection(self, direction):
+        self.target = tuple(float(x) for x in direction)
+        self.target_is_direction = True
+
+    def SetAspect(self, aspect):
+        self.aspect = float(aspect)
+
+    def SetFOVY(self, fovy):
+        self.fovy = float(fovy)
+
+    def SetRoll(self, roll):
+        self.roll = float(roll)
+
+
+class Variable:
+    """One shader variable; assigning .value updates the renderer (the reference's UI
+    writes through a raw pointer into the map, VariableManager.cpp:105,157)."""
+
+    def __init__(self, owner, name, c):
+        self._owner, self.name = owner, name
+        self.minval, self.maxval, self.start, self.step = c.minval, c.maxval, c.start, c.step
+
+    @property
+    def value(self):
+        out = ctypes.c_float()
+        self._owner._check(self._owner._L.sdfr_var_get(self._owner._h, self.name.encode(), ctypes.byref(out)))
+        return out.value
+
+    @value.setter
+    def value(self, v):
+        self._owner._check(self._owner._L.sdfr_var_set(self._owner._h, self.name.encode(), float(v)))
+
+    def __repr__(self):
+        return "Variable(%s: min=%g max=%g start=%g step=%g value=%g)" % (self.name, self.minval, self.maxval, self.start, self.step, self.value)
+
+
+class SDFRenderer:
+    """The SDF render stage.  Mirrors Engine/SDFRenderer.h:17-44."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        self._h = ctypes.c_void_p()
+        self._stime = 0.0
+        self.init(device)
+
+    # bool init(Graphics&) -- here: bind to a GPU
+    def init(self, device=0):
+        if self._h:
+            self._L.sdfr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        rc = self._L.sdfr_create(int(device), ctypes.byref(self._h))
+        if rc != SDFR_OK:
+            raise SdfrError(rc, "sdfr_create(device=%d) failed" % device)
+        self.device = int(device)
+        return True
+
+    def close(self):
+        if self._h:
+            self._L.sdfr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SDFR_OK:
+            raise SdfrError(rc, self._L.sdfr_last_error(self._h).decode())
+
+    # bool initShader(ShaderIncluder&) with the scene substitution of Application::loadScene
+    def initShader(self, scene):
+        self._check(self._L.sdfr_load_scene(self._h, scene.encode()))
+        return True
+
+    loadScene = initShader
+
+    def currentScene(self):
+        s = self._L.sdfr_current_scene(self._h)
+        return s.decode() if s else None
+
+    # void setParameters(float stime)
+    def setParameters(self, stime):
+        self._stime = float(stime)
+        self._check(self._L.sdfr_set_time(self._h, self._stime))
+
+    # VariableMap &getVariableMap(): ordered like std::map
+    def getVariableMap(self):
+        out = {}
+        for i in range(self._L.sdfr_var_count(self._h)):
+            c = _CVariable()
+            self._check(self._L.sdfr_var_info(self._h, i, ctypes.byref(c)))
+            out[c.name.decode()] = Variable(self, c.name.decode(), c)
+        return out
+
+    def setValue(self, name, value):
+        """ShaderVariableManager::setValue: unknown names are ignored (returns False)."""
+        rc = self._L.sdfr_var_set(self._h, name.encode(), float(value))
+        if rc == -3:
+            return False
+        self._check(rc)
+        return True
+
+    def resetVariables(self):
+        self._check(self._L.sdfr_vars_reset(self._h))
+
+    def setCamera(self, camera):
+        fn = self._L.sdfr_set_camera_direction if camera.target_is_direction else self._L.sdfr_set_camera_lookat
+        self._check(fn(self._h, _f3(camera.eye), _f3(camera.target), camera.fovy, camera.aspect, camera.roll))
+
+    def setCameraBasis(self, eye, front, right, top):
+        """The raw constant-buffer form (SDFRenderer.h:29-34)."""
+        self._check(self._L.sdfr_set_camera(self._h, _f3(eye), _f3(front), _f3(right), _f3(top)))
+
+    def getCameraBasis(self):
+        out = (ctypes.c_float * 12)()
+        self._check(self._L.sdfr_get_camera(self._h, out))
+        return np.array(out, np.float32).reshape(4, 3)
+
+    def getLimits(self):
+        l = Limits()
+        self._check(self._L.sdfr_get_limits(self._h, ctypes.byref(l)))
+        return l
+
+    def setLimits(self, **kw):
+        l = self.getLimits()
+        for k, v in kw.items():
+            if not hasattr(l, k):
+                raise AttributeError(k)
+            setattr(l, k, v)
+        self._check(self._L.sdfr_set_limits(self._h, ctypes.byref(l)))
+
+    def setSchedule(self, schedule):
+        self._check(self._L.sdfr_set_schedule(self._h, int(schedule)))
+
+    def setProfiling(self, enabled):
+        self._check(self._L.sdfr_set_profiling(self._h, 1 if enabled else 0))
+
+    def setStream(self, stream_handle):
+        self._check(self._L.sdfr_set_stream(self._h, ctypes.c_void_p(stream_handle)))
+
+    # bool render(FullscreenQuad&, GPUProfiler&, Camera&)
+    def render(self, camera=None, width=1200, height=800, out=None, fmt=RGBA32F, pixel_stats=False):
+        """Renders one frame.  `out` may be a CUDA/HIP torch tensor ([H,W,4] float32 or
+        float16) -> device-to-device, asynchronous on the renderer's stream; otherwise a host
+        numpy array is returned (synchronous).  With pixel_stats=True also returns
+        [H,W,3] uint32 {rays, march evaluations, hits} (host path only)."""
+        if camera is not None:
+            self.setCamera(camera)
+        if out is not None and hasattr(out, "data_ptr"):
+            assert out.is_cuda and out.is_contiguous() and out.numel() == width * height * 4
+            self._check(self._L.sdfr_render(self._h, width, height, ctypes.c_void_p(out.data_ptr()), fmt, 0, None))
+            return out
+        dt = np.float32 if fmt == RGBA32F else np.float16
+        img = np.zeros((height, width, 4), dt) if out is None else out
+        st = np.zeros((height, width, 3), np.uint32) if pixel_stats else None
+        self._check(self._L.sdfr_render(self._h, width, height, img.ctypes.data_as(ctypes.c_void_p), fmt, 1,
+                                        st.ctypes.data_as(ctypes.c_void_p) if pixel_stats else None))
+        return (img, st) if pixel_stats else img
+
+    def renderStrips(self, width, height, rank, world, out, fmt=RGBA32F):
+        """Multi-GPU: render this rank's 8-row strips into the compact device tensor `out`."""
+        assert out.is_cuda and out.is_contiguous() and out.numel() == strip_buffer_pixels(width, height, world) * 4
+        self._check(self._L.sdfr_render_strips(self._h, width, height, rank, world, ctypes.c_void_p(out.data_ptr()), fmt))
+        return out
+
+    def assembleStrips(self, width, height, world, gathered, out, fmt=RGBA32F):
+        self._check(self._L.sdfr_assemble_strips(self._h, width, height, world, ctypes.c_void_p(gathered.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()), fmt))
+        return out
+
+    def sync(self):
+        self._check(self._L.sdfr_sync(self._h))
+
+    def getStats(self):
+        s = Stats()
+        self._check(self._L.sdfr_get_stats(self._h, ctypes.byref(s)))
+        return s
+
+
+def assemble_strips_host(width, height, world, gathered):
+    """Host (numpy) statement of the strip layout: gathered[world, strip_buffer_pixels, C] ->
+    image[height, width, C].  Used by the CPU tests of the multi-rank path; the GPU path is
+    sdfr_assemble_strips."""
+    gathered = np.asarray(gathered)
+    C = gathered.shape[-1]
+    per_rank_rows = strip_buffer_pixels_host(width, height, world) // width
+    g = gathered.reshape(world, per_rank_rows, width, C)
+    img = np.zeros((height, width, C), gathered.dtype)
+    for py in range(height):
+        strip = py // STRIP_ROWS
+        img[py] = g[strip % world, (strip // world) * STRIP_ROWS + py % STRIP_ROWS]
+    return img
+
+
+def strip_buffer_pixels_host(width, height, world):
+    strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
+    return ((strips + world - 1) // world) * STRIP_ROWS * width
+
+
+def strip_rows_of_rank(height, rank, world):
+    """Global rows owned by `rank`, in the order they appear in its compact buffer."""
+    rows = []
+    strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
+    for s in range(rank, strips, world):
+        for k in range(STRIP_ROWS):
+            if s * STRIP_ROWS + k < height:
+                rows.append(s * STRIP_ROWS + k)
+    return rows

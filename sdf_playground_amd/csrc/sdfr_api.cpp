@@ -1,0 +1,526 @@
+// sdfr_api.cpp -- implementation of the C ABI declared in include/sdfr.h.
+//
+// Host logic only: handle state (scene, variable table, camera, limits), per-frame uniform
+// preparation, device buffers and launches.  All pixels are produced by the HIP kernels in
+// sdfr_kernels.hip; there is no CPU rendering path.
+#include "../../include/sdfr.h"
+
+#include "sdfr_hostframe.h"
+#include "sdfr_hostlib.h"
+#include "sdfr_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sdfr;
+
+// VAR_ tags of the raymarch driver itself (reference: pshader_sdf.hlsl:88-90,97-99,108,142)
+static const char *k_driver_variables =
+	"VAR_debug_x(min = -10, max = +10, step = 0.02) VAR_debug_y(min = -10, max = +10, step = 0.02) "
+	"VAR_debug_z(min = -10, max = +10, step = 0.02) VAR_debug_nx(min = -1, max = +1, step = 0.02) "
+	"VAR_debug_ny(min = -1, max = +1, step = 0.02) VAR_debug_nz(min = -1, max = +1, step = 0.02) "
+	"VAR_show_objects(min = 0, max = 1, step = 1, start = 1) VAR_debug_scale(min = 0.005, max = 2, step = 0.005, start = 0.2)";
+
+struct sdfr_renderer
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int scene = -1;
+	int schedule = SDFR_SCHEDULE_WAVEFRONT;
+	bool profiling = false;
+	FrameU U;
+	host::ShaderVariableManager vars;
+	std::vector<std::string> scene_var_slots; // slot k of FrameU::scene_var <- this variable
+	mutable std::string error;
+
+	RenderTotals *d_totals = nullptr;
+	WavefrontWorkspace ws = {};
+	void *d_stage = nullptr; // staging image for host-destination renders
+	size_t stage_bytes = 0;
+	uint32_t *d_pstat = nullptr;
+	size_t pstat_bytes = 0;
+
+	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	hipEvent_t ev_march[32] = {}, ev_shade[32] = {};
+	int last_rounds = 0;
+	bool have_render = false;
+	bool last_wavefront = false;
+	bool last_profiled = false;
+};
+
+static int fail(const sdfr_renderer *r, int code, const std::string &msg)
+{
+	if (r) r->error = msg;
+	return code;
+}
+static int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
+{
+	return fail(r, SDFR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SDFR_HIP(call) \
+	do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(r, e_, #call); } while (0)
+
+static void free_workspace(sdfr_renderer *r)
+{
+	WavefrontWorkspace &w = r->ws;
+	hipFree(w.ray_cur);
+	hipFree(w.ray_queue);
+	hipFree(w.qdepth_lo);
+	hipFree(w.qdepth_hi);
+	hipFree(w.result);
+	hipFree(w.accum);
+	hipFree(w.list_a);
+	hipFree(w.list_b);
+	hipFree(w.counters);
+	w = WavefrontWorkspace{};
+}
+
+static int ensure_workspace(sdfr_renderer *r, size_t pixels)
+{
+	if (r->ws.capacity >= pixels) return SDFR_OK;
+	free_workspace(r);
+	WavefrontWorkspace w = {};
+	w.capacity = pixels;
+	SDFR_HIP(hipMalloc((void **)&w.ray_cur, sizeof(float) * 11 * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.ray_queue, sizeof(float) * 11 * SDFR_MAX_RAYS * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.qdepth_lo, sizeof(uint32_t) * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.qdepth_hi, sizeof(uint32_t) * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.result, sizeof(float) * 8 * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.accum, sizeof(float) * 4 * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.list_a, sizeof(uint32_t) * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.list_b, sizeof(uint32_t) * pixels));
+	SDFR_HIP(hipMalloc((void **)&w.counters, sizeof(uint32_t) * 64));
+	w.pstat = nullptr;
+	r->ws = w;
+	return SDFR_OK;
+}
+
+extern "C" {
+
+int sdfr_create(int device_ordinal, sdfr_renderer **out)
+{
+	if (!out) return SDFR_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
+	if (device_ordinal < 0 || device_ordinal >= count) return SDFR_ERR_INVALID_ARGUMENT;
+	if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
+	sdfr_renderer *r = new sdfr_renderer();
+	r->device = device_ordinal;
+	frame_defaults(r->U);
+	// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
+	host::Camera cam;
+	cam.SetAspect(1200.f / 800.f);
+	cam.SetFOVY(60.f * 3.14159265358979f / 180.f);
+	cam.SetRoll(0.f);
+	cam.SetEye(host::Vec3(0.f, 2.f, -3.f));
+	cam.SetLookat(host::Vec3(0.f, 1.f, 0.f));
+	host::Vec3 e, f, rt, tp;
+	cam.GetBasis(e, f, rt, tp);
+	r->U.eye = V3(e.x, e.y, e.z);
+	r->U.front = V3(f.x, f.y, f.z);
+	r->U.right = V3(rt.x, rt.y, rt.z);
+	r->U.top = V3(tp.x, tp.y, tp.z);
+	if (hipMalloc((void **)&r->d_totals, sizeof(RenderTotals)) != hipSuccess || hipEventCreate(&r->ev_begin) != hipSuccess ||
+		hipEventCreate(&r->ev_end) != hipSuccess)
+	{
+		delete r;
+		return SDFR_ERR_HIP;
+	}
+	for (int i = 0; i < 32; ++i)
+	{
+		hipEventCreate(&r->ev_march[i]);
+		hipEventCreate(&r->ev_shade[i]);
+	}
+	*out = r;
+	return SDFR_OK;
+}
+
+void sdfr_destroy(sdfr_renderer *r)
+{
+	if (!r) return;
+	hipSetDevice(r->device);
+	hipStreamSynchronize(r->stream);
+	free_workspace(r);
+	hipFree(r->d_totals);
+	hipFree(r->d_stage);
+	hipFree(r->d_pstat);
+	hipEventDestroy(r->ev_begin);
+	hipEventDestroy(r->ev_end);
+	for (int i = 0; i < 32; ++i)
+	{
+		hipEventDestroy(r->ev_march[i]);
+		hipEventDestroy(r->ev_shade[i]);
+	}
+	delete r;
+}
+
+const char *sdfr_last_error(const sdfr_renderer *r) { return r ? r->error.c_str() : "null handle"; }
+
+int sdfr_set_stream(sdfr_renderer *r, void *hip_stream)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	r->stream = (hipStream_t)hip_stream;
+	return SDFR_OK;
+}
+
+int sdfr_scene_count(void) { return SDFR_SCENE_COUNT; }
+const char *sdfr_scene_name(int index) { return scene_name(index); }
+
+int sdfr_load_scene(sdfr_renderer *r, const char *name)
+{
+	if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
+	const int idx = scene_index(name);
+	if (idx < 0) return fail(r, SDFR_ERR_UNKNOWN_SCENE, std::string("unknown scene '") + name + "'");
+	// rebuild the variable table like SDFRenderer::initShader: clear, then collect the tags of
+	// the driver and of the scene
+	host::ShaderVariableManager vm;
+	const std::string scene_tags = scene_variables(idx);
+	if (!vm.parseFile(std::string(k_driver_variables) + " " + scene_tags))
+		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag");
+	// scene slots: distinct names of the scene's tags in order of appearance
+	host::ShaderVariableManager scene_only;
+	scene_only.parseFile(scene_tags);
+	std::vector<std::string> slots;
+	{
+		std::vector<std::string_view> code, tags;
+		host::split_tagged(scene_tags, "VAR_", ")", code, tags);
+		for (std::string_view t : tags)
+		{
+			std::string nm(t.substr(4, t.find('(') - 4));
+			bool seen = false;
+			for (const auto &s : slots) seen = seen || s == nm;
+			if (!seen) slots.push_back(nm);
+		}
+	}
+	if (slots.size() > SDFR_MAX_SCENE_VARS) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "too many scene variables");
+	r->vars = vm;
+	r->scene_var_slots = slots;
+	r->scene = idx;
+	return SDFR_OK;
+}
+
+const char *sdfr_current_scene(const sdfr_renderer *r) { return (r && r->scene >= 0) ? scene_name(r->scene) : nullptr; }
+
+int sdfr_var_count(const sdfr_renderer *r) { return r ? (int)r->vars.getVariables().size() : SDFR_ERR_INVALID_ARGUMENT; }
+
+int sdfr_var_info(const sdfr_renderer *r, int index, sdfr_variable *out)
+{
+	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	const auto &m = r->vars.getVariables();
+	if (index < 0 || index >= (int)m.size()) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "variable index out of range");
+	auto it = m.begin();
+	std::advance(it, index);
+	memset(out, 0, sizeof *out);
+	snprintf(out->name, sizeof out->name, "%s", it->first.c_str());
+	out->minval = it->second.minval;
+	out->maxval = it->second.maxval;
+	out->start = it->second.start;
+	out->step = it->second.step;
+	out->value = it->second.value;
+	return SDFR_OK;
+}
+
+int sdfr_var_set(sdfr_renderer *r, const char *name, float value)
+{
+	if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
+	if (!r->vars.setValue(name, value)) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "' (ignored)");
+	return SDFR_OK;
+}
+
+int sdfr_var_get(const sdfr_renderer *r, const char *name, float *out)
+{
+	if (!r || !name || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	const auto &m = r->vars.getVariables();
+	auto it = m.find(std::string_view(name));
+	if (it == m.end()) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "'");
+	*out = it->second.value;
+	return SDFR_OK;
+}
+
+int sdfr_vars_reset(sdfr_renderer *r)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	for (auto &kv : r->vars.getVariables()) kv.second.value = kv.second.start;
+	return SDFR_OK;
+}
+
+int sdfr_set_camera(sdfr_renderer *r, const float eye[3], const float front[3], const float right[3], const float top[3])
+{
+	if (!r || !eye || !front || !right || !top) return SDFR_ERR_INVALID_ARGUMENT;
+	r->U.eye = V3(eye[0], eye[1], eye[2]);
+	r->U.front = V3(front[0], front[1], front[2]);
+	r->U.right = V3(right[0], right[1], right[2]);
+	r->U.top = V3(top[0], top[1], top[2]);
+	return SDFR_OK;
+}
+
+static int set_camera_from(sdfr_renderer *r, const host::Camera &cam)
+{
+	host::Vec3 e, f, rt, tp;
+	cam.GetBasis(e, f, rt, tp);
+	r->U.eye = V3(e.x, e.y, e.z);
+	r->U.front = V3(f.x, f.y, f.z);
+	r->U.right = V3(rt.x, rt.y, rt.z);
+	r->U.top = V3(tp.x, tp.y, tp.z);
+	return SDFR_OK;
+}
+
+int sdfr_set_camera_lookat(sdfr_renderer *r, const float eye[3], const float lookat[3], float fovy, float aspect, float roll)
+{
+	if (!r || !eye || !lookat) return SDFR_ERR_INVALID_ARGUMENT;
+	host::Camera cam;
+	cam.SetAspect(aspect);
+	cam.SetFOVY(fovy);
+	cam.SetRoll(roll);
+	cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
+	cam.SetLookat(host::Vec3(lookat[0], lookat[1], lookat[2]));
+	return set_camera_from(r, cam);
+}
+
+int sdfr_set_camera_direction(sdfr_renderer *r, const float eye[3], const float direction[3], float fovy, float aspect, float roll)
+{
+	if (!r || !eye || !direction) return SDFR_ERR_INVALID_ARGUMENT;
+	host::Camera cam;
+	cam.SetAspect(aspect);
+	cam.SetFOVY(fovy);
+	cam.SetRoll(roll);
+	cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
+	cam.SetDirection(host::Vec3(direction[0], direction[1], direction[2]));
+	return set_camera_from(r, cam);
+}
+
+int sdfr_get_camera(const sdfr_renderer *r, float out[12])
+{
+	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	const vec3 v[4] = {r->U.eye, r->U.front, r->U.right, r->U.top};
+	for (int i = 0; i < 4; ++i)
+	{
+		out[3 * i + 0] = v[i].x;
+		out[3 * i + 1] = v[i].y;
+		out[3 * i + 2] = v[i].z;
+	}
+	return SDFR_OK;
+}
+
+int sdfr_set_time(sdfr_renderer *r, float stime)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	r->U.stime = stime;
+	return SDFR_OK;
+}
+
+int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out)
+{
+	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	out->iter_count = r->U.iter_count;
+	out->bounce_count = r->U.bounce_count;
+	out->ray_count = r->U.ray_count;
+	out->light_count = r->U.light_count;
+	out->range = r->U.range;
+	out->max_cost_default = (int)r->U.max_cost_default;
+	return SDFR_OK;
+}
+
+int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
+{
+	if (!r || !l) return SDFR_ERR_INVALID_ARGUMENT;
+	if (l->iter_count < 1 || l->iter_count > 0xffffff || l->bounce_count < 0 || l->bounce_count > 16 || l->ray_count < 1 ||
+		l->ray_count > SDFR_MAX_RAYS || l->light_count < 0 || l->light_count > SDFR_MAX_LIGHTS || l->max_cost_default < 0 ||
+		l->max_cost_default > 250 || !(l->range == l->range))
+		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
+	r->U.iter_count = l->iter_count;
+	r->U.bounce_count = l->bounce_count;
+	r->U.ray_count = l->ray_count;
+	r->U.light_count = l->light_count;
+	r->U.range = l->range;
+	r->U.max_cost_default = (uint32_t)l->max_cost_default;
+	return SDFR_OK;
+}
+
+int sdfr_set_profiling(sdfr_renderer *r, int enabled)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	r->profiling = enabled != 0;
+	return SDFR_OK;
+}
+
+int sdfr_set_schedule(sdfr_renderer *r, int schedule)
+{
+	if (!r || (schedule != SDFR_SCHEDULE_WAVEFRONT && schedule != SDFR_SCHEDULE_PIXEL)) return SDFR_ERR_INVALID_ARGUMENT;
+	r->schedule = schedule;
+	return SDFR_OK;
+}
+
+int64_t sdfr_strip_buffer_pixels(int width, int height, int world)
+{
+	if (width < 1 || height < 1 || world < 1) return 0;
+	const int64_t strips = ((int64_t)height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS;
+	return ((strips + world - 1) / world) * SDFR_STRIP_ROWS * (int64_t)width;
+}
+
+// latch the variable values into the frame uniforms (the reference uploads them every frame,
+// SDFRenderer.cpp:75-78) and derive the per-frame constants
+static int latch_frame(sdfr_renderer *r, int width, int height)
+{
+	if (r->scene < 0) return fail(r, SDFR_ERR_NO_SCENE, "no scene loaded");
+	if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
+	FrameU &U = r->U;
+	U.width = width;
+	U.height = height;
+	const auto &m = r->vars.getVariables();
+	auto val = [&](const char *n) { auto it = m.find(std::string_view(n)); return it != m.end() ? it->second.value : 0.f; };
+	U.debug_nx = val("debug_nx");
+	U.debug_ny = val("debug_ny");
+	U.debug_nz = val("debug_nz");
+	U.debug_scale = val("debug_scale");
+	U.debug_x = val("debug_x");
+	U.debug_y = val("debug_y");
+	U.debug_z = val("debug_z");
+	U.show_objects = val("show_objects");
+	for (int i = 0; i < SDFR_MAX_SCENE_VARS; ++i) U.scene_var[i] = 0.f;
+	for (size_t k = 0; k < r->scene_var_slots.size(); ++k) U.scene_var[k] = val(r->scene_var_slots[k].c_str());
+	frame_derive(U, r->scene);
+	return SDFR_OK;
+}
+
+static int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats)
+{
+	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	if (world < 1 || rank < 0 || rank >= world) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad rank/world");
+	int rc = latch_frame(r, width, height);
+	if (rc != SDFR_OK) return rc;
+	SDFR_HIP(hipSetDevice(r->device));
+
+	RowMap rm;
+	rm.rank = rank;
+	rm.world = world;
+	rm.local_rows = (int)(sdfr_strip_buffer_pixels(width, height, world) / width);
+	if (world == 1) rm.local_rows = height;
+	const size_t local_pixels = (size_t)rm.local_rows * width;
+	const size_t bpp = format == SDFR_RGBA32F ? 16 : 8;
+
+	void *d_out = out;
+	uint32_t *d_pstat = pixel_stats;
+	if (out_on_host)
+	{
+		if (r->stage_bytes < local_pixels * bpp)
+		{
+			hipFree(r->d_stage);
+			r->d_stage = nullptr;
+			r->stage_bytes = 0;
+			SDFR_HIP(hipMalloc(&r->d_stage, local_pixels * bpp));
+			r->stage_bytes = local_pixels * bpp;
+		}
+		d_out = r->d_stage;
+		if (pixel_stats)
+		{
+			if (r->pstat_bytes < local_pixels * 12)
+			{
+				hipFree(r->d_pstat);
+				r->d_pstat = nullptr;
+				r->pstat_bytes = 0;
+				SDFR_HIP(hipMalloc((void **)&r->d_pstat, local_pixels * 12));
+				r->pstat_bytes = local_pixels * 12;
+			}
+			d_pstat = r->d_pstat;
+		}
+	}
+	if (world > 1) // strips past the end of the frame are never written: define them
+		SDFR_HIP(hipMemsetAsync(d_out, 0, local_pixels * bpp, r->stream));
+
+	SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream));
+	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
+	hipError_t e;
+	if (r->schedule == SDFR_SCHEDULE_PIXEL)
+	{
+		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->stream);
+		r->last_wavefront = false;
+	}
+	else
+	{
+		const size_t tiles = (((size_t)width + 7) / 8) * (((size_t)rm.local_rows + 7) / 8);
+		rc = ensure_workspace(r, tiles * 64);
+		if (rc != SDFR_OK) return rc;
+		e = launch_wavefront_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream, r->profiling ? r->ev_march : nullptr,
+			r->profiling ? r->ev_shade : nullptr, &r->last_rounds);
+		r->last_wavefront = true;
+		r->last_profiled = r->profiling;
+	}
+	if (e != hipSuccess) return hip_fail(r, e, "kernel launch");
+	SDFR_HIP(hipEventRecord(r->ev_end, r->stream));
+	r->have_render = true;
+
+	if (out_on_host)
+	{
+		SDFR_HIP(hipMemcpyAsync(out, d_out, local_pixels * bpp, hipMemcpyDeviceToHost, r->stream));
+		if (pixel_stats) SDFR_HIP(hipMemcpyAsync(pixel_stats, d_pstat, local_pixels * 12, hipMemcpyDeviceToHost, r->stream));
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+	}
+	return SDFR_OK;
+}
+
+int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
+{
+	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats);
+}
+
+int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format)
+{
+	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr);
+}
+
+int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format)
+{
+	if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
+	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	SDFR_HIP(hipSetDevice(r->device));
+	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->stream);
+	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
+	return SDFR_OK;
+}
+
+int sdfr_sync(sdfr_renderer *r)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	SDFR_HIP(hipStreamSynchronize(r->stream));
+	return SDFR_OK;
+}
+
+int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out)
+{
+	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	memset(out, 0, sizeof *out);
+	if (!r->have_render) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "nothing rendered yet");
+	SDFR_HIP(hipEventSynchronize(r->ev_end));
+	float ms = 0.f;
+	SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
+	out->ms_gpu = ms;
+	RenderTotals t;
+	SDFR_HIP(hipMemcpy(&t, r->d_totals, sizeof t, hipMemcpyDeviceToHost));
+	out->pixels = t.pixels;
+	out->rays = t.rays;
+	out->march_evals = t.march_evals;
+	out->hits = t.hits;
+	if (r->last_wavefront)
+	{
+		for (int i = 0; r->last_profiled && i < r->last_rounds && i < 16; ++i)
+		{
+			float a = 0.f, b = 0.f;
+			if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) == hipSuccess) out->ms_march += a;
+			if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) == hipSuccess) out->ms_shade += b;
+		}
+		out->march_launches = (uint32_t)r->last_rounds;
+		out->shade_launches = (uint32_t)r->last_rounds;
+	}
+	else
+	{
+		out->march_launches = 1;
+	}
+	return SDFR_OK;
+}
+
+} // extern "C"

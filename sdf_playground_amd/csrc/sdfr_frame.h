@@ -1,0 +1,86 @@
+// sdfr_frame.h -- per-frame uniform block and the small records exchanged between the
+// pipeline stages (device code, host-compilable).
+#pragma once
+#include "sdfr_math.h"
+
+namespace sdfr {
+
+enum { SDFR_MAX_RAYS = 8, SDFR_MAX_LIGHTS = 8, SDFR_MAX_SCENE_VARS = 8, SDFR_SCENE_UNIFORMS = 48 };
+
+// Frame uniforms = the reference's camera constant buffer b0 (pshader_sdf.hlsl:17-26), its
+// VAR_ buffer b1 (ShaderUtil.cpp:193-267), the driver's compile-time limits
+// (pshader_sdf.hlsl:60-64,350) as run-time values, plus values derived once per frame on the
+// host.  Passed to kernels by value: it is wave-uniform, so it lives in SGPRs.
+struct FrameU
+{
+	vec3 eye, front, right, top;
+	float stime;
+	int width, height;
+	int iter_count, bounce_count, ray_count, light_count;
+	float range;
+	uint32_t max_cost_default;
+	// driver variables (pshader_sdf.hlsl:88-108,142)
+	float debug_nx, debug_ny, debug_nz, debug_scale, debug_x, debug_y, debug_z, show_objects;
+	float scene_var[SDFR_MAX_SCENE_VARS];
+	// ---- derived on the host (sdfr_derive_frame) ----
+	vec3 debug_normal;   // normalised debug-plane normal, or 0
+	int debug_plane_on;  // any(debug normal)
+	int show_on;         // any(show_objects)
+	float ddx, ddy;      // screen-space derivatives of the NDC coordinate: 2/W, -2/H
+	float sky_s, sky_c;  // sin/cos(-stime * 0.025) for the shared sky
+	float su[SDFR_SCENE_UNIFORMS]; // scene-specific constants (Scene::prepare)
+};
+
+// One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct
+// (pshader_sdf.hlsl:40-51) is not stored: it is `pos` when has_transparent is set and 0
+// otherwise (pshader_sdf.hlsl:377,401,415,494,578,610).
+struct RayRec
+{
+	vec3 pos, dir, contrib;
+	float shadow_range;
+	uint32_t bits; // [7:0] depth cost, [8] inside (inside_sign = -1), [9] has_transparent, [10] is_shadow_ray
+};
+enum { RAY_INSIDE = 1u << 8, RAY_TRANSPARENT = 1u << 9, RAY_SHADOW = 1u << 10, RAY_DEPTH_MASK = 0xffu, RAY_DEPTH_INVALID = 0xffu };
+
+SDF_HD uint32_t ray_depth(const RayRec &r) { return r.bits & RAY_DEPTH_MASK; }
+SDF_HD float ray_inside_sign(const RayRec &r) { return (r.bits & RAY_INSIDE) ? -1.f : 1.f; }
+SDF_HD bool ray_is_shadow(const RayRec &r) { return (r.bits & RAY_SHADOW) != 0; }
+SDF_HD bool ray_has_transparent(const RayRec &r) { return (r.bits & RAY_TRANSPARENT) != 0; }
+
+// the MarchingInput of the scene ABI (sdf_structs.hlsl:23-37) as derived from a queued ray
+struct RayFlags { bool has_transparent; bool is_shadow; vec3 last_transparent_pos; };
+
+// what a scene's material callback sees of the hit point (GeometryInput with dir.w = 0)
+struct SurfacePoint
+{
+	vec3 pos, dir;
+	float camera_distance;
+	vec3 right_off, bottom_off; // pixel footprint per unit of distance
+};
+
+// MaterialOutput of the scene ABI (sdf_structs.hlsl:66-110), defaults of pshader_sdf.hlsl:338-351
+struct Material
+{
+	uint32_t id;
+	vec3 mpos;       // material_position.xyz
+	float prop_x;    // material_properties.x
+	vec4 diffuse;    // rgb + alpha
+	vec4 specular;   // rgb + power
+	vec3 emissive, reflection, refraction;
+	float ior;
+	vec4 normal;     // xyz + blend
+	uint32_t max_cost;
+	bool use_hdr;
+};
+
+// LightOutput of the scene ABI (sdf_structs.hlsl:112-130)
+struct Light
+{
+	vec3 pos;
+	bool directional; // pos.w == 1
+	float extend;
+	vec3 color;
+	float falloff;
+};
+
+} // namespace sdfr

@@ -1,0 +1,72 @@
+// sdfr_hostframe.h -- host side of the frame uniforms: reference defaults, the values
+// derived once per frame, and the per-scene prepare() dispatch.
+#pragma once
+#include "sdfr_perpixel.h"
+
+namespace sdfr {
+
+// reference limits (pshader_sdf.hlsl:60-64,350) and driver-variable defaults (F10 rules
+// applied to pshader_sdf.hlsl:88-108,142)
+inline void frame_defaults(FrameU &U)
+{
+	memset(&U, 0, sizeof U);
+	U.iter_count = 100;
+	U.bounce_count = 16;
+	U.ray_count = 8;
+	U.light_count = 8;
+	U.range = 100.f;
+	U.max_cost_default = 7;
+	U.debug_scale = 0.2f;
+	U.show_objects = 1.f;
+}
+
+inline void frame_derive(FrameU &U, int scene_index)
+{
+	vec3 n = V3(U.debug_nx, U.debug_ny, U.debug_nz);
+	U.debug_plane_on = any3(n) ? 1 : 0;
+	U.debug_normal = U.debug_plane_on ? normalize(n) : V3s(0.f);
+	U.show_on = (U.show_objects != 0.f) ? 1 : 0;
+	U.ddx = 2.f / (float)U.width;
+	U.ddy = -2.f / (float)U.height;
+	vec2 sc = sincos1(-U.stime * 0.025f);
+	U.sky_s = sc.x;
+	U.sky_c = sc.y;
+	for (int i = 0; i < SDFR_SCENE_UNIFORMS; ++i)
+		U.su[i] = 0.f;
+	switch (scene_index)
+	{
+#define SDFR_PREP(I, S) case I: S::prepare(U); break;
+		SDFR_FOR_EACH_SCENE(SDFR_PREP)
+#undef SDFR_PREP
+	default: break;
+	}
+}
+
+inline const char *scene_name(int i)
+{
+	switch (i)
+	{
+#define SDFR_NAME(I, S) case I: return S::name();
+		SDFR_FOR_EACH_SCENE(SDFR_NAME)
+#undef SDFR_NAME
+	default: return nullptr;
+	}
+}
+inline const char *scene_variables(int i)
+{
+	switch (i)
+	{
+#define SDFR_VARS(I, S) case I: return S::variables();
+		SDFR_FOR_EACH_SCENE(SDFR_VARS)
+#undef SDFR_VARS
+	default: return "";
+	}
+}
+inline int scene_index(const char *name)
+{
+	for (int i = 0; i < SDFR_SCENE_COUNT; ++i)
+		if (strcmp(scene_name(i), name) == 0) return i;
+	return -1;
+}
+
+} // namespace sdfr

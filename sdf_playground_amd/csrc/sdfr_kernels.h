@@ -1,0 +1,54 @@
+// sdfr_kernels.h -- host-callable launchers of the gfx950 kernels (sdfr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdfr_frame.h"
+
+namespace sdfr {
+
+// device-side totals of one render
+struct RenderTotals
+{
+	unsigned long long pixels, rays, march_evals, hits;
+};
+
+// Which rows of the full frame this launch renders: local row l is global row
+// ((l / 8) * world + rank) * 8 + l % 8 (8-row strips dealt round-robin over ranks).
+// world = 1, rank = 0 is the whole frame.
+struct RowMap
+{
+	int local_rows;
+	int rank, world;
+};
+
+enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1 };
+
+// per-handle scratch of the wavefront schedule (allocated by the API, sized for `capacity` pixels)
+struct WavefrontWorkspace
+{
+	size_t capacity;     // pixels
+	float *ray_cur;      // [11][capacity] ray being traced for each pixel
+	float *ray_queue;    // [8][11][capacity] pending rays
+	uint32_t *qdepth_lo; // [capacity] packed depths of slots 0-3
+	uint32_t *qdepth_hi; // [capacity] packed depths of slots 4-7
+	float *result;       // [8][capacity] march result: status/iter, t, d, normal xyz (+2 spare)
+	float *accum;        // [4][capacity] rgb accumulator + hdr flag
+	uint32_t *pstat;     // [3][capacity] per-pixel counters
+	uint32_t *list_a;    // [capacity] pixels with a ray in flight (ping)
+	uint32_t *list_b;    // [capacity] (pong)
+	uint32_t *counters;  // [64] list sizes per round and misc
+};
+
+hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, hipStream_t stream);
+
+hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
+	int *n_rounds_out);
+
+hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream);
+
+int device_cu_count(int device);
+
+} // namespace sdfr

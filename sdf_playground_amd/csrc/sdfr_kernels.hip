@@ -1,0 +1,568 @@
+// sdfr_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the SDF raymarch renderer.
+//
+// Two schedules of the same pipeline stages (sdfr_pixel.h); both produce identical pixels.
+//
+//  * WAVEFRONT (default).  The path is VALU-bound: what matters is keeping all
+//    64 lanes of every wave busy although rays need 1..iter_count steps.  Per bounce round:
+//      k_march  persistent waves; every lane sphere-traces ONE ray at a time and, when its ray
+//               ends (hit: plus the 3 forward-difference normal samples, taken in the same
+//               loop so the scene function stays convergent), goes idle; when a ballot shows
+//               enough idle lanes the wave refills them from its next chunk of the round's
+//               ray list.  Ray records live in HBM as structure-of-arrays, so a refill reads
+//               consecutive addresses.  No atomics in the loop: wave w owns chunks
+//               w, w + NW, w + 2 NW, ... of 64 rays, which also samples the whole image
+//               uniformly per wave (load balance).
+//      k_shade  one lane per finished ray: material, lighting, secondary-ray spawn into the
+//               pixel's 8-slot queue (HBM), pop of the pixel's next ray, append to the next
+//               round's list with ONE atomic per block.
+//    Rounds are bounded by bounce_count (16); the list sizes stay on the device, empty
+//    rounds cost a few microseconds each.
+//
+//  * PIXEL.  One lane per pixel runs the reference's bounce loop start to finish
+//    (sdfr_perpixel.h).  Divergent; kept as correctness anchor and A/B baseline.
+//
+// Everything wave-uniform (camera, variables, limits, per-frame scene constants) travels as
+// a by-value kernel argument and therefore sits in SGPRs.
+#include "sdfr_kernels.h"
+#include "sdfr_perpixel.h"
+
+#include <hip/hip_fp16.h>
+
+namespace sdfr {
+
+#define SDFR_BLOCK 256
+#define SDFR_INVALID_PIXEL 0xffffffffu
+// refill a march wave once this many lanes are idle (or when all are)
+#define SDFR_REFILL_THRESHOLD 16
+
+// ---- pixel mapping ------------------------------------------------------------------------------
+// Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
+// neighbouring pixels (coherent materials, similar step counts).
+struct PixelCoord
+{
+	int px, py;   // in the full frame
+	uint32_t pid; // index in this launch's (compact) image
+};
+__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc)
+{
+	const uint32_t tiles_x = ((uint32_t)U.width + 7u) >> 3;
+	const uint32_t tile = w >> 6, lane = w & 63u;
+	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+	const int px = (int)(tx * 8u + (lane & 7u));
+	const int lrow = (int)(ty * 8u + (lane >> 3));
+	if (px >= U.width || lrow >= rm.local_rows) return false;
+	const int py = ((lrow >> 3) * rm.world + rm.rank) * 8 + (lrow & 7);
+	if (py >= U.height) return false;
+	pc.px = px;
+	pc.py = py;
+	pc.pid = (uint32_t)lrow * (uint32_t)U.width + (uint32_t)px;
+	return true;
+}
+__device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, uint32_t pid, int &px, int &py)
+{
+	const uint32_t lrow = pid / (uint32_t)U.width;
+	px = (int)(pid - lrow * (uint32_t)U.width);
+	py = (int)(((lrow >> 3) * (uint32_t)rm.world + (uint32_t)rm.rank) * 8u + (lrow & 7u));
+}
+static uint32_t work_items(const FrameU &U, const RowMap &rm)
+{
+	const uint32_t tiles_x = ((uint32_t)U.width + 7u) >> 3;
+	const uint32_t tiles_y = ((uint32_t)rm.local_rows + 7u) >> 3;
+	return tiles_x * tiles_y * 64u;
+}
+
+__device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid, vec4 c)
+{
+	if (format == FORMAT_RGBA32F)
+	{
+		reinterpret_cast<float4 *>(out)[pid] = make_float4(c.x, c.y, c.z, c.w);
+	}
+	else
+	{
+		__half2 lo = __floats2half2_rn(c.x, c.y);
+		__half2 hi = __floats2half2_rn(c.z, c.w);
+		uint2 v;
+		v.x = *reinterpret_cast<uint32_t *>(&lo);
+		v.y = *reinterpret_cast<uint32_t *>(&hi);
+		reinterpret_cast<uint2 *>(out)[pid] = v;
+	}
+}
+
+// block-wide sum of three counters into the render totals: one atomic triple per block
+__device__ __forceinline__ void block_add_totals(RenderTotals *totals, uint32_t pixels, uint32_t rays, uint32_t evals, uint32_t hits)
+{
+	__shared__ unsigned long long acc[4];
+	if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+	__syncthreads();
+	// wave reduction by DPP-free shuffles
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		pixels += __shfl_down(pixels, off);
+		rays += __shfl_down(rays, off);
+		evals += __shfl_down(evals, off);
+		hits += __shfl_down(hits, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		atomicAdd(&acc[0], (unsigned long long)pixels);
+		atomicAdd(&acc[1], (unsigned long long)rays);
+		atomicAdd(&acc[2], (unsigned long long)evals);
+		atomicAdd(&acc[3], (unsigned long long)hits);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		if (acc[0]) atomicAdd(&totals->pixels, acc[0]);
+		if (acc[1]) atomicAdd(&totals->rays, acc[1]);
+		if (acc[2]) atomicAdd(&totals->march_evals, acc[2]);
+		if (acc[3]) atomicAdd(&totals->hits, acc[3]);
+	}
+}
+
+// =================================================================================================
+// PIXEL schedule
+// =================================================================================================
+template <class Scene, bool DBG>
+__global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals)
+{
+	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
+	PixelCounters c = {0, 0, 0};
+	uint32_t npix = 0;
+	PixelCoord pc;
+	if (w < n_work && work_to_pixel(U, rm, w, pc))
+	{
+		vec4 v = render_pixel<Scene, DBG>(U, pc.px, pc.py, c);
+		store_pixel(out, format, pc.pid, v);
+		if (pixel_stats)
+		{
+			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;
+			pixel_stats[3 * (size_t)pc.pid + 1] = c.march_evals;
+			pixel_stats[3 * (size_t)pc.pid + 2] = c.hits;
+		}
+		npix = 1;
+	}
+	block_add_totals(totals, npix, c.rays, c.march_evals, c.hits);
+}
+
+// =================================================================================================
+// WAVEFRONT schedule
+// =================================================================================================
+// ray record field order in the SoA arrays
+enum { RF_PX = 0, RF_PY, RF_PZ, RF_DX, RF_DY, RF_DZ, RF_CX, RF_CY, RF_CZ, RF_RANGE, RF_BITS, RF_COUNT };
+// march result fields
+enum { RS_STATUS = 0, RS_T, RS_D, RS_NX, RS_NY, RS_NZ, RS_COUNT };
+// counters[]: [r] = size of round r's list (r = 0..16)
+enum { CNT_ROUND0 = 0 };
+
+__device__ __forceinline__ RayRec load_ray(const float *base, size_t cap, uint32_t pid)
+{
+	RayRec r;
+	r.pos = V3(base[RF_PX * cap + pid], base[RF_PY * cap + pid], base[RF_PZ * cap + pid]);
+	r.dir = V3(base[RF_DX * cap + pid], base[RF_DY * cap + pid], base[RF_DZ * cap + pid]);
+	r.contrib = V3(base[RF_CX * cap + pid], base[RF_CY * cap + pid], base[RF_CZ * cap + pid]);
+	r.shadow_range = base[RF_RANGE * cap + pid];
+	r.bits = __float_as_uint(base[RF_BITS * cap + pid]);
+	return r;
+}
+__device__ __forceinline__ void store_ray(float *base, size_t cap, uint32_t pid, const RayRec &r)
+{
+	base[RF_PX * cap + pid] = r.pos.x;
+	base[RF_PY * cap + pid] = r.pos.y;
+	base[RF_PZ * cap + pid] = r.pos.z;
+	base[RF_DX * cap + pid] = r.dir.x;
+	base[RF_DY * cap + pid] = r.dir.y;
+	base[RF_DZ * cap + pid] = r.dir.z;
+	base[RF_CX * cap + pid] = r.contrib.x;
+	base[RF_CY * cap + pid] = r.contrib.y;
+	base[RF_CZ * cap + pid] = r.contrib.z;
+	base[RF_RANGE * cap + pid] = r.shadow_range;
+	base[RF_BITS * cap + pid] = __uint_as_float(r.bits);
+}
+
+// ---- k_init: primary rays, empty queues, cleared accumulators, round-0 list ---------------------
+__global__ __launch_bounds__(SDFR_BLOCK) void k_init(FrameU U, RowMap rm, uint32_t n_work, WavefrontWorkspace ws, uint32_t *pixel_stats)
+{
+	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
+	if (w == 0)
+	{
+		ws.counters[CNT_ROUND0] = n_work;
+		for (int r = 1; r <= 16; ++r) ws.counters[r] = 0;
+	}
+	if (w >= n_work) return;
+	PixelCoord pc;
+	if (!work_to_pixel(U, rm, w, pc))
+	{
+		ws.list_a[w] = SDFR_INVALID_PIXEL;
+		return;
+	}
+	const size_t cap = ws.capacity;
+	const PixelRay pr = pixel_ray(U, pc.px, pc.py);
+	store_ray(ws.ray_cur, cap, pc.pid, primary_ray(U, pr));
+	ws.qdepth_lo[pc.pid] = 0xffffffffu;
+	ws.qdepth_hi[pc.pid] = 0xffffffffu;
+	ws.accum[0 * cap + pc.pid] = 0.f;
+	ws.accum[1 * cap + pc.pid] = 0.f;
+	ws.accum[2 * cap + pc.pid] = 0.f;
+	ws.accum[3 * cap + pc.pid] = -1.f; // hdr_output "not set" (pshader_sdf.hlsl:284)
+	ws.list_a[w] = pc.pid;
+	if (pixel_stats)
+	{
+		pixel_stats[3 * (size_t)pc.pid + 0] = 0;
+		pixel_stats[3 * (size_t)pc.pid + 1] = 0;
+		pixel_stats[3 * (size_t)pc.pid + 2] = 0;
+	}
+}
+
+// ---- k_march ----------------------------------------------------------------------------------------
+enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_GRAD0 = 2, LANE_GRAD1 = 3, LANE_GRAD2 = 4 };
+
+template <class Scene, bool DBG>
+__global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
+	const uint32_t *__restrict__ n_ptr, uint32_t *pixel_stats, RenderTotals *totals)
+{
+	const uint32_t n = *n_ptr;
+	const size_t cap = ws.capacity;
+	const DebugFlags F = debug_flags(U);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t nwaves = (gridDim.x * SDFR_BLOCK) >> 6;
+	uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * SDFR_BLOCK + threadIdx.x) >> 6);
+	// [next, end) = unconsumed part of this wave's current chunk of the list (wave-uniform)
+	uint32_t next = chunk * 64u;
+	uint32_t end = next + 64u < n ? next + 64u : n;
+
+	int state = LANE_IDLE;
+	uint32_t pid = 0;
+	March m = march_begin(V3s(0.f), V3s(0.f));
+	typename Scene::RayInv R = {};
+	float inside_sign = 1.f, max_range = 0.f, baseline = 0.f, g0 = 0.f, g1 = 0.f;
+	uint32_t evals = 0;       // of the current ray
+	uint32_t tot_evals = 0, tot_hits = 0;
+
+	for (;;)
+	{
+		const unsigned long long idle = __ballot(state == LANE_IDLE);
+		if (idle)
+		{
+			const bool more = next < n;
+			const uint32_t n_idle = (uint32_t)__popcll(idle);
+			if (!more)
+			{
+				if (n_idle == 64u) break; // list drained and every lane finished
+			}
+			else if (n_idle >= SDFR_REFILL_THRESHOLD || n_idle == 64u)
+			{
+				// hand the next list entries to the idle lanes, in lane order
+				const uint32_t avail = end - next;
+				if (state == LANE_IDLE)
+				{
+					const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+					if (rank < avail)
+					{
+						const uint32_t p = list[next + rank];
+						if (p != SDFR_INVALID_PIXEL)
+						{
+							pid = p;
+							const RayRec ray = load_ray(ws.ray_cur, cap, pid);
+							R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
+							inside_sign = ray_inside_sign(ray);
+							max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
+							m = march_begin(ray.pos, ray.dir);
+							evals = 0;
+							state = LANE_MARCH;
+						}
+					}
+				}
+				const uint32_t taken = n_idle < avail ? n_idle : avail;
+				next += taken;
+				if (next == end)
+				{
+					chunk += nwaves;
+					next = chunk * 64u;
+					if (next > n) next = n;
+					end = next + 64u < n ? next + 64u : n;
+				}
+			}
+		}
+
+		if (state != LANE_IDLE)
+		{
+			// one scene-distance evaluation per lane: a march sample or a normal sample
+			const bool marching = state == LANE_MARCH;
+			if (marching) march_pre(m);
+			const vec3 hp = march_pos(m);
+			vec3 p = hp;
+			if (state == LANE_GRAD0) p = grad_sample_pos(hp, 0, SDFR_GRAD_EPS);
+			if (state == LANE_GRAD1) p = grad_sample_pos(hp, 1, SDFR_GRAD_EPS);
+			if (state == LANE_GRAD2) p = grad_sample_pos(hp, 2, SDFR_GRAD_EPS);
+			const float dist = map_geometry<Scene, DBG>(U, F, R, p, m.dir, marching);
+
+			if (marching)
+			{
+				evals++;
+				const int status = march_advance(m, dist * inside_sign, max_range, (uint32_t)U.iter_count);
+				if (status == MARCH_HIT)
+				{
+					baseline = m.d * inside_sign;
+					state = LANE_GRAD0;
+				}
+				else if (status == MARCH_MISS)
+				{
+					ws.result[RS_STATUS * cap + pid] = __uint_as_float((uint32_t)MARCH_MISS << 24 | m.iter);
+					tot_evals += evals;
+					if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
+					state = LANE_IDLE;
+				}
+			}
+			else if (state == LANE_GRAD0)
+			{
+				g0 = dist - baseline;
+				state = LANE_GRAD1;
+			}
+			else if (state == LANE_GRAD1)
+			{
+				g1 = dist - baseline;
+				state = LANE_GRAD2;
+			}
+			else
+			{
+				const vec3 nrm = normalize(V3(g0, g1, dist - baseline));
+				ws.result[RS_STATUS * cap + pid] = __uint_as_float((uint32_t)MARCH_HIT << 24 | m.iter);
+				ws.result[RS_T * cap + pid] = m.t;
+				ws.result[RS_D * cap + pid] = m.d;
+				ws.result[RS_NX * cap + pid] = nrm.x;
+				ws.result[RS_NY * cap + pid] = nrm.y;
+				ws.result[RS_NZ * cap + pid] = nrm.z;
+				tot_evals += evals;
+				tot_hits += 1;
+				if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
+				state = LANE_IDLE;
+			}
+		}
+	}
+	block_add_totals(totals, 0, 0, tot_evals, tot_hits);
+}
+
+// ---- k_shade -----------------------------------------------------------------------------------------
+struct GlobalRayStore
+{
+	float *queue;
+	size_t cap;
+	uint32_t pid;
+	__device__ __forceinline__ void put(int slot, const RayRec &r) { store_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid, r); }
+};
+
+template <class Scene, bool DBG>
+__global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
+	const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ next_list, uint32_t *next_n, int round, void *out, int format,
+	uint32_t *pixel_stats, RenderTotals *totals)
+{
+	const uint32_t n = *n_ptr;
+	const size_t cap = ws.capacity;
+	const DebugFlags F = debug_flags(U);
+	__shared__ uint32_t s_count, s_base;
+	uint32_t n_rays = 0, n_done = 0;
+
+	for (uint32_t base = blockIdx.x * SDFR_BLOCK; base < n; base += gridDim.x * SDFR_BLOCK)
+	{
+		if (threadIdx.x == 0) s_count = 0;
+		__syncthreads();
+		const uint32_t i = base + threadIdx.x;
+		uint32_t pid = SDFR_INVALID_PIXEL;
+		if (i < n) pid = list[i];
+		bool alive = false;
+		if (pid != SDFR_INVALID_PIXEL)
+		{
+			n_rays++;
+			const RayRec ray = load_ray(ws.ray_cur, cap, pid);
+			int px, py;
+			pid_to_pixel(U, rm, pid, px, py);
+			const PixelRay pr = pixel_ray(U, px, py);
+			const uint32_t status_iter = __float_as_uint(ws.result[RS_STATUS * cap + pid]);
+			const uint32_t status = status_iter >> 24, iter = status_iter & 0xffffffu;
+
+			uint64_t depths = (uint64_t)ws.qdepth_lo[pid] | ((uint64_t)ws.qdepth_hi[pid] << 32);
+			int count = 0;
+			for (int s = 0; s < SDFR_MAX_RAYS; ++s)
+				count += (((depths >> (8 * s)) & 0xffu) != RAY_DEPTH_INVALID) ? 1 : 0;
+			float hdr = ws.accum[3 * cap + pid];
+
+			vec3 add;
+			if (status == MARCH_HIT)
+			{
+				HitInfo hit;
+				hit.t = ws.result[RS_T * cap + pid];
+				hit.d = ws.result[RS_D * cap + pid];
+				hit.iter = iter;
+				hit.normal = V3(ws.result[RS_NX * cap + pid], ws.result[RS_NY * cap + pid], ws.result[RS_NZ * cap + pid]);
+				hit.pos = mad(ray.dir, hit.t, ray.pos);
+				const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
+				GlobalRayStore store = {ws.ray_queue, cap, pid};
+				Spawner<GlobalRayStore> q(store, depths, count, U.ray_count);
+				add = shade_hit<Scene, DBG, GlobalRayStore>(U, F, ray, pr, hit, max_range, hdr, q);
+				depths = q.depths;
+				count = q.count;
+				if (pixel_stats) pixel_stats[3 * (size_t)pid + 2] += 1;
+			}
+			else
+			{
+				add = shade_miss<Scene>(U, ray, iter);
+			}
+			const vec3 acc = V3(ws.accum[0 * cap + pid], ws.accum[1 * cap + pid], ws.accum[2 * cap + pid]) + add;
+			if (pixel_stats) pixel_stats[3 * (size_t)pid + 0] += 1;
+
+			if (count > 0 && round + 1 < U.bounce_count)
+			{
+				// pop the pixel's next ray: it is traced in the next round
+				const int slot = queue_next(depths, U.ray_count);
+				const RayRec nr = load_ray(ws.ray_queue + (size_t)slot * RF_COUNT * cap, cap, pid);
+				store_ray(ws.ray_cur, cap, pid, nr);
+				depths = queue_set_depth(depths, slot, RAY_DEPTH_INVALID);
+				ws.qdepth_lo[pid] = (uint32_t)depths;
+				ws.qdepth_hi[pid] = (uint32_t)(depths >> 32);
+				ws.accum[0 * cap + pid] = acc.x;
+				ws.accum[1 * cap + pid] = acc.y;
+				ws.accum[2 * cap + pid] = acc.z;
+				ws.accum[3 * cap + pid] = hdr;
+				alive = true;
+			}
+			else
+			{
+				store_pixel(out, format, pid, V4(acc.x, acc.y, acc.z, abs1(hdr)));
+				n_done++;
+			}
+		}
+		// append the surviving pixels to the next round's list: one atomic per block
+		uint32_t my_off = 0;
+		if (alive) my_off = atomicAdd(&s_count, 1u);
+		__syncthreads();
+		if (threadIdx.x == 0 && s_count) s_base = atomicAdd(next_n, s_count);
+		__syncthreads();
+		if (alive) next_list[s_base + my_off] = pid;
+		__syncthreads();
+	}
+	block_add_totals(totals, n_done, n_rays, 0, 0);
+}
+
+// ---- strip assembly on the root (multi-GPU) ---------------------------------------------------------
+// gathered[rank][local pixel] -> image[global pixel]; bytes_per_pixel = 16 or 8
+__global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, int world, size_t strip_pixels, const uint32_t *gathered,
+	uint32_t *image, int words_per_pixel)
+{
+	const size_t total = (size_t)width * (size_t)height;
+	for (size_t g = (size_t)blockIdx.x * SDFR_BLOCK + threadIdx.x; g < total; g += (size_t)gridDim.x * SDFR_BLOCK)
+	{
+		const uint32_t py = (uint32_t)(g / (size_t)width), px = (uint32_t)(g - (size_t)py * width);
+		const uint32_t strip = py >> 3;
+		const uint32_t rank = strip % (uint32_t)world, local_strip = strip / (uint32_t)world;
+		const size_t lrow = (size_t)local_strip * 8u + (py & 7u);
+		const size_t src = (size_t)rank * strip_pixels + lrow * (size_t)width + px;
+		for (int k = 0; k < words_per_pixel; ++k)
+			image[g * words_per_pixel + k] = gathered[src * words_per_pixel + k];
+	}
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+int device_cu_count(int device)
+{
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256;
+	return prop.multiProcessorCount;
+}
+
+template <class Scene, bool DBG>
+static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
+	hipStream_t stream)
+{
+	const uint32_t n_work = work_items(U, rm);
+	const uint32_t blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, totals);
+	return hipGetLastError();
+}
+
+hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, hipStream_t stream)
+{
+	switch (scene)
+	{
+#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_pixel<S, true>(U, rows, out, format, pixel_stats, totals, stream) : run_pixel<S, false>(U, rows, out, format, pixel_stats, totals, stream);
+		SDFR_FOR_EACH_SCENE(SDFR_RUN)
+#undef SDFR_RUN
+	default: return hipErrorInvalidValue;
+	}
+}
+
+template <class Scene, bool DBG>
+static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
+	const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events, int *n_rounds_out)
+{
+	const uint32_t n_work = work_items(U, rm);
+	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue; // lists are indexed by work item, state by pixel id < n_work
+	const uint32_t init_blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
+	hipLaunchKernelGGL(k_init, dim3(init_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, ws, pixel_stats);
+
+	int device = 0;
+	(void)hipGetDevice(&device);
+	const int cus = device_cu_count(device);
+	int march_blocks_per_cu = 0, shade_blocks_per_cu = 0;
+	(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&march_blocks_per_cu, k_march<Scene, DBG>, SDFR_BLOCK, 0);
+	(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_blocks_per_cu, k_shade<Scene, DBG>, SDFR_BLOCK, 0);
+	if (march_blocks_per_cu < 1) march_blocks_per_cu = 1;
+	if (shade_blocks_per_cu < 1) shade_blocks_per_cu = 1;
+	// persistent grids: exactly what is resident, but never more waves than chunks of work
+	const uint32_t chunks = (n_work + 63u) / 64u;
+	uint32_t march_blocks = (uint32_t)(cus * march_blocks_per_cu);
+	if (march_blocks > (chunks + 3u) / 4u) march_blocks = (chunks + 3u) / 4u;
+	if (march_blocks < 1) march_blocks = 1;
+	uint32_t shade_blocks = (uint32_t)(cus * shade_blocks_per_cu);
+	if (shade_blocks > init_blocks) shade_blocks = init_blocks;
+	if (shade_blocks < 1) shade_blocks = 1;
+
+	uint32_t *list_cur = ws.list_a, *list_next = ws.list_b;
+	const int rounds = U.bounce_count;
+	for (int r = 0; r < rounds; ++r)
+	{
+		if (march_events) (void)hipEventRecord(march_events[2 * r], stream);
+		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, ws, list_cur, ws.counters + r, pixel_stats, totals);
+		if (march_events) (void)hipEventRecord(march_events[2 * r + 1], stream);
+		if (shade_events) (void)hipEventRecord(shade_events[2 * r], stream);
+		hipLaunchKernelGGL((k_shade<Scene, DBG>), dim3(shade_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, ws, list_cur, ws.counters + r, list_next,
+			ws.counters + r + 1, r, out, format, pixel_stats, totals);
+		if (shade_events) (void)hipEventRecord(shade_events[2 * r + 1], stream);
+		uint32_t *t = list_cur;
+		list_cur = list_next;
+		list_next = t;
+	}
+	if (n_rounds_out) *n_rounds_out = rounds;
+	return hipGetLastError();
+}
+
+hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
+	int *n_rounds_out)
+{
+	switch (scene)
+	{
+#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_wavefront<S, true>(U, rows, out, format, pixel_stats, totals, ws, stream, march_events, shade_events, n_rounds_out) : run_wavefront<S, false>(U, rows, out, format, pixel_stats, totals, ws, stream, march_events, shade_events, n_rounds_out);
+		SDFR_FOR_EACH_SCENE(SDFR_RUN)
+#undef SDFR_RUN
+	default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream)
+{
+	const int words = format == FORMAT_RGBA32F ? 4 : 2;
+	const size_t strips = ((size_t)height + 7) / 8;
+	const size_t strip_pixels = ((strips + world - 1) / world) * 8 * (size_t)width;
+	const size_t total = (size_t)width * height;
+	uint32_t blocks = (uint32_t)((total + SDFR_BLOCK - 1) / SDFR_BLOCK);
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(SDFR_BLOCK), 0, stream, width, height, world, strip_pixels,
+		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), words);
+	return hipGetLastError();
+}
+
+} // namespace sdfr

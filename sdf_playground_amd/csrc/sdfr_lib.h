@@ -1,0 +1,300 @@
+// sdfr_lib.h -- SDF primitives, domain operators, floor/sky helpers and procedural
+// materials used by the scene functors (device code, host-compilable).
+//
+// Functionality mirrors the reference shader libraries so that scenes keep their meaning:
+//   primitives  Engine/shader/sdf_primitives.hlsl:6-131
+//   operators   Engine/shader/sdf_ops.hlsl:6-134
+//   floor/sky   Engine/shader/sdf_common.hlsl:4-94
+//   materials   Engine/shader/sdf_materials.hlsl:6-31,143-201
+// Per-frame uniform sines/cosines are passed in pre-computed (see Scene::prepare).
+#pragma once
+#include "sdfr_math.h"
+#include "sdfr_noise.h"
+
+namespace sdfr {
+
+// epsilons of the reference driver (pshader_sdf.hlsl:31-35)
+#define SDFR_DIST_EPS 0.0001f
+#define SDFR_GRAD_EPS 0.0001f
+#define SDFR_REFLECT_EPS 0.001f
+#define SDFR_REFRACT_EPS 0.001f
+#define SDFR_SHADOW_EPS 0.0003f
+
+#define SDFR_SQRT_HALF 0.70710678118654752f
+#define SDFR_SQRT_TWO 1.41421356237309504f
+#define SDFR_PI 3.14159265358979323f
+#define SDFR_TAU 6.28318530717958647f
+
+// material ids (pshader_sdf.hlsl:67-76)
+enum MaterialId
+{
+	MAT_NONE = 0, MAT_PLAIN = 1, MAT_ITER = 2, MAT_NORMAL1 = 3, MAT_NORMAL2 = 4, MAT_DISTANCE_PLANE = 5,
+	MAT_WOOD = 20, MAT_MARBLE_DARK = 21, MAT_MARBLE_LIGHT = 22, MAT_FIRE = 23
+};
+
+SDF_HD bool on_surface(float d) { return abs1(d) < SDFR_DIST_EPS; }
+
+// ---- primitives ------------------------------------------------------------------------
+SDF_HD float sd_sphere(vec3 p, float r) { return length(p) - r; }
+
+// analytic ray/sphere distance when `fast`, exact SDF otherwise (sdf_primitives.hlsl:11-45)
+SDF_HD float sd_sphere_fast(vec3 p, vec3 dir, bool fast, float r)
+{
+	if (!fast) return sd_sphere(p, r);
+	float b = -dot(p, dir);
+	float c = dot(p, p) - r * r;
+	float disc = b * b - c;
+	if (disc < 0.f) return 1e10f;
+	float root = sqrt1(disc);
+	float t1 = b - root;
+	float t2 = b + root;
+	if (t1 < -SDFR_DIST_EPS) return t2 > 0.f ? t2 : 1e10f;
+	return t1;
+}
+
+SDF_HD float sd_box(vec3 p, vec3 half_size)
+{
+	vec3 q = abs(p) - half_size;
+	return length(max(q, 0.f)) + min1(max1(q.x, max1(q.y, q.z)), 0.f);
+}
+
+SDF_HD float sd_plane(vec3 p, vec3 n) { return dot(p, n); }
+
+// distance along the ray when `fast` (sdf_primitives.hlsl:59-70)
+SDF_HD float sd_plane_fast(vec3 p, vec3 dir, bool fast, vec3 n)
+{
+	float d = dot(p, n);
+	if (fast) return d / (sat1(dot(dir, -n)) + 1e-20f);
+	return d;
+}
+
+SDF_HD float sd_torus_xy(vec3 p, float r_big, float r_small)
+{
+	vec2 q = V2(length(V2(p.x, p.y)) - r_big, p.z);
+	return length(q) - r_small;
+}
+
+SDF_HD float sd_capped_cylinder(vec3 p, float h, float r)
+{
+	vec2 d = abs(V2(length(V2(p.x, p.z)), p.y)) - V2(r, h);
+	return min1(max1(d.x, d.y), 0.f) + length(max(d, 0.f));
+}
+
+SDF_HD float sd_round_cone(vec3 p, vec3 a, vec3 b, float r1, float r2)
+{
+	vec3 ba = b - a;
+	float l2 = dot(ba, ba);
+	float rr = r1 - r2;
+	float a2 = l2 - rr * rr;
+	float il2 = 1.0f / l2;
+
+	vec3 pa = p - a;
+	float y = dot(pa, ba);
+	float z = y - l2;
+	vec3 xs = pa * l2 - ba * y;
+	float x2 = dot(xs, xs);
+	float y2 = y * y * l2;
+	float z2 = z * z * l2;
+
+	float k = sign1(rr) * rr * rr * x2;
+	if (sign1(z) * a2 * z2 > k) return sqrt1(x2 + z2) * il2 - r2;
+	if (sign1(y) * a2 * y2 < k) return sqrt1(x2 + y2) * il2 - r1;
+	return (sqrt1(x2 * a2 * il2) + y * rr) * il2 - r1;
+}
+
+// guard objects: distance along the ray to the wall of a repetition cell
+SDF_HD float sd_limit1(float p, float dir, float lim)
+{
+	return ((step1(0.f, dir) - 0.5f) * lim - p) / dir;
+}
+SDF_HD float sd_limit2(vec2 p, vec2 dir, vec2 lim)
+{
+	vec2 t = ((V2(step1(0.f, dir.x), step1(0.f, dir.y)) - 0.5f) * lim - p) / dir;
+	return min1(t.x, t.y);
+}
+SDF_HD float sd_limit3(vec3 p, vec3 dir, vec3 lim)
+{
+	vec3 t = ((V3(step1(0.f, dir.x), step1(0.f, dir.y), step1(0.f, dir.z)) - 0.5f) * lim - p) / dir;
+	return min1(min1(t.x, t.y), t.z);
+}
+
+// ---- operators -------------------------------------------------------------------------
+SDF_HD float op_rep_lim(float p, float count, float size)
+{
+	float rounded = size * (rne1(p / size + count / 2.f) - count / 2.f);
+	float limit = count * size * 0.5f;
+	return p - clamp1(rounded, -limit, limit);
+}
+SDF_HD vec2 op_rep_lim(vec2 p, vec2 count, vec2 size) { return V2(op_rep_lim(p.x, count.x, size.x), op_rep_lim(p.y, count.y, size.y)); }
+SDF_HD vec3 op_rep_lim(vec3 p, vec3 count, vec3 size) { return V3(op_rep_lim(p.x, count.x, size.x), op_rep_lim(p.y, count.y, size.y), op_rep_lim(p.z, count.z, size.z)); }
+
+SDF_HD float op_rep_inf(float p, float size)
+{
+	float x = p + size * 0.5f;
+	return x - size * floor1(x / size) - size * 0.5f;
+}
+SDF_HD vec2 op_rep_inf(vec2 p, vec2 size) { return V2(op_rep_inf(p.x, size.x), op_rep_inf(p.y, size.y)); }
+SDF_HD vec3 op_rep_inf(vec3 p, vec3 size) { return V3(op_rep_inf(p.x, size.x), op_rep_inf(p.y, size.y), op_rep_inf(p.z, size.z)); }
+
+// angular repetition; folds `p` into the first sector, returns the sector index
+SDF_HD float op_rep_angle(vec2 *p, float count)
+{
+	float angle = atan21(p->y, p->x);
+	float reduced = angle * count / SDFR_TAU + 0.5f;
+	float index = floor1(reduced);
+	reduced = reduced - index;
+	angle = (reduced - 0.5f) * SDFR_TAU / count;
+	vec2 sc = sincos1(angle);
+	*p = V2(sc.y, sc.x) * length(*p);
+	return index;
+}
+
+// rotation with pre-computed sine/cosine
+SDF_HD vec2 rot2(vec2 p, float s, float c) { return V2(p.x * c - p.y * s, p.x * s + p.y * c); }
+SDF_HD vec2 op_rotate(vec2 p, float angle)
+{
+	vec2 sc = sincos1(angle);
+	return rot2(p, sc.x, sc.y);
+}
+
+SDF_HD float op_shell(float d, float inner, float outer)
+{
+	float avg = (outer + inner) * 0.5f;
+	float diff = (outer - inner) * 0.5f;
+	return abs1(d - avg) - diff;
+}
+
+SDF_HD vec2 op_ab2uv(vec2 v) { return V2(v.x + v.y, v.x - v.y) * SDFR_SQRT_HALF; }
+SDF_HD float op_chamfer(float a, float b, float size) { return (a + b - size) * SDFR_SQRT_HALF; }
+SDF_HD float op_chamfer_merge(float a, float b, float size) { return min1(min1(a, b), op_chamfer(a, b, size)); }
+
+SDF_HD float op_pipe(float a, float b, float size, float count)
+{
+	vec2 uv = op_ab2uv(V2(a, b));
+	float diag = size * SDFR_SQRT_HALF - uv.y;
+	diag = fmod1(diag, SDFR_SQRT_TWO * size / count);
+	uv.y = size * SDFR_SQRT_HALF - diag;
+	vec2 ab = op_ab2uv(uv);
+	float a_offset = (count - 1.f) / count;
+	return length(V2(ab.x - a_offset * size, ab.y)) - size / count;
+}
+SDF_HD float op_pipe_merge(float a, float b, float size, float count) { return min1(min1(a, b), op_pipe(a, b, size, count)); }
+
+SDF_HD float op_staircase(float x, float stepval, float spread)
+{
+	return min1(stepval, frac1(x / spread) * spread) + floor1(x / spread) * stepval;
+}
+SDF_HD float op_smin(float a, float b, float k)
+{
+	float h = sat1(0.5f + 0.5f * (b - a) / k);
+	return lerp1(b, a, h) - k * h * (1.f - h);
+}
+SDF_HD float op_smax1(float a, float b, float k)
+{
+	float h = sat1(0.5f - 0.5f * (b + a) / k);
+	return lerp1(b, -a, h) + k * h * (1.f - h);
+}
+SDF_HD float op_smax2(float a, float b, float k)
+{
+	float h = sat1(0.5f - 0.5f * (b - a) / k);
+	return lerp1(b, a, h) + k * h * (1.f - h);
+}
+
+// ---- colour helpers --------------------------------------------------------------------
+SDF_HD vec3 hue_to_rgb(float H)
+{
+	float R = abs1(H * 6.f - 3.f) - 1.f;
+	float G = 2.f - abs1(H * 6.f - 2.f);
+	float B = 2.f - abs1(H * 6.f - 4.f);
+	return saturate(V3(R, G, B));
+}
+SDF_HD vec3 hsv_to_rgb(vec3 hsv) { return ((hue_to_rgb(hsv.x) - 1.f) * hsv.y + 1.f) * hsv.z; }
+SDF_HD float rgb_to_brightness(vec3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }
+
+// ---- checker floor with 4-tap footprint anti-aliasing (sdf_common.hlsl:24-60) -----------
+SDF_HD vec4 checker_tap(vec3 p, vec3 dir)
+{
+	float to_move = p.y / dir.y;
+	vec2 q = V2(p.x, p.z) - V2(dir.x, dir.z) * to_move;
+	vec2 idx = floor(q);
+	vec2 in_tile = q - idx;
+	float parity = rne1(frac1((idx.x + idx.y) * 0.5f + 0.25f));
+	float grey = parity > 0.5f ? 0.1f : 0.8f;
+	vec2 border = 0.5f - abs(in_tile - 0.5f);
+	return V4(grey, grey, grey, min1(border.x, border.y));
+}
+SDF_HD vec3 checker_color(vec3 p, vec3 dir, vec3 off_right, vec3 off_bottom)
+{
+	vec4 c1 = checker_tap(p, dir);
+	vec4 c2 = checker_tap(p + off_right, dir);
+	vec4 c3 = checker_tap(p + off_bottom, dir);
+	vec4 c4 = checker_tap(p + off_bottom + off_right, dir);
+	float total = c1.w + c2.w + c3.w + c4.w;
+	vec3 sum = V3(c1.x, c1.y, c1.z) * c1.w + V3(c2.x, c2.y, c2.z) * c2.w + V3(c3.x, c3.y, c3.z) * c3.w + V3(c4.x, c4.y, c4.z) * c4.w;
+	return sum / total;
+}
+
+// sky (sdf_common.hlsl:85-94) with the frame-uniform rotation sin/cos(-stime*0.025) passed in
+SDF_HD vec3 sky_color(vec3 dir, float rot_s, float rot_c)
+{
+	vec2 r = rot2(V2(dir.x, dir.z), rot_s, rot_c);
+	dir.x = r.x;
+	dir.z = r.y;
+	float n = turbulence3(dir * V3(1.f, 6.f, 1.f) * 2.5f);
+	vec3 blue = V3(43.f, 164.f, 247.f) / 255.f;
+	vec3 white = V3(212.f, 224.f, 238.f) / 255.f;
+	vec3 sky = lerp(blue, white, n) * 1.2f;
+	return lerp(V3s(0.25f), sky, sat1(dir.y * 8.f + 0.125f));
+}
+
+// ---- procedural materials (sdf_materials.hlsl:6-31) --------------------------------------
+SDF_HD vec3 mat_marble(vec3 p, vec3 tint)
+{
+	float wave = dot(V3(3.f, 2.f, 1.f), p) * 2.f + turbulence3(p) * 5.f;
+	float s = (1.f + sin1(wave)) * 0.5f;
+	s = pow1(s, 0.5f);
+	return tint * s;
+}
+SDF_HD vec3 mat_wood(vec3 p)
+{
+	float dist = sqrt1(p.x * p.x + p.y * p.y) + 0.125f * turbulence3(p);
+	float s = 0.5f * abs1(sin1(2.f * 12.f * dist * 3.14159f));
+	return V3(0.3125f + s, 0.117f + s, 0.117f);
+}
+SDF_HD vec4 mat_fire(vec3 p, float threshold)
+{
+	float turb = turbulence3(p) + 0.35f;
+	turb = turb > threshold ? turb : 0.f;
+	return V4(5.f * turb, 2.f * turb, 1.f * turb, 0.5f * turb);
+}
+
+// debug visualisations (sdf_materials.hlsl:143-186)
+SDF_HD vec3 mat_debug_plane(float d)
+{
+	float ip;
+	float fr = abs1(modf1(d, &ip)) * 1.2f;
+	float band = modf1(ip / 5.f, &ip);
+	vec3 band_color = band > 0.7f ? V3(1.f, 0.25f, 0.25f) : V3(0.75f, 0.75f, 1.f);
+	fr = d < 25.f ? fr : 0.5f;
+	vec3 col = fr < 1.f ? fr * fr * V3s(1.f) : band_color;
+	col.y = d < 0.f ? (d > -0.01f ? 1.f : 0.f) : col.y;
+	return col;
+}
+SDF_HD vec3 mat_iter_heat(uint32_t iter, uint32_t max_iter)
+{
+	float rel = (float)iter / (float)max_iter;
+	if (rel < 0.1f) return lerp(V3(0.f, 0.f, 0.f), V3(0.f, 0.f, 1.f), rel / 0.1f);
+	if (rel < 0.5f) return lerp(V3(0.f, 0.f, 1.f), V3(0.f, 1.f, 0.f), (rel - 0.1f) / 0.4f);
+	if (rel < 0.9f) return lerp(V3(0.f, 1.f, 0.f), V3(1.f, 1.f, 0.f), (rel - 0.5f) / 0.4f);
+	return lerp(V3(1.f, 1.f, 0.f), V3(1.f, 0.f, 0.f), (rel - 0.9f) / 0.1f);
+}
+SDF_HD float mat_coordinate_grid(vec3 p, vec3 n, float width)
+{
+	vec3 r = p - floor(p);
+	r = abs(r - 0.5f);
+	vec3 tick = saturate((r - 0.5f + width) * 100.f);
+	vec3 mask = 1.f - abs(n);
+	return dot(tick, mask);
+}
+
+} // namespace sdfr

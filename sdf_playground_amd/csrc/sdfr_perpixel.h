@@ -1,0 +1,90 @@
+// sdfr_perpixel.h -- the whole pipeline for ONE pixel, start to finish, on one lane.
+//
+// Used by the "pixel" kernel (one lane per pixel; the simple, divergent schedule kept as the
+// correctness anchor and as the A/B baseline for the wavefront kernels) and by
+// tests/hostsim, which compiles it for the CPU to bit-compare the pipeline stages with the
+// oracle where no GPU is available.  The schedule follows the reference's bounce loop
+// (pshader_sdf.hlsl:286-634) literally.
+#pragma once
+#include "sdfr_pixel.h"
+#include "sdfr_scenes.h"
+
+namespace sdfr {
+
+struct LocalRayStore
+{
+	RayRec slot[SDFR_MAX_RAYS];
+	SDF_HD void put(int i, const RayRec &r) { slot[i] = r; }
+};
+
+struct PixelCounters { uint32_t rays, march_evals, hits; };
+
+template <class Scene, bool DBG>
+SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt)
+{
+	const DebugFlags F = debug_flags(U);
+	const PixelRay pr = pixel_ray(U, px, py);
+	LocalRayStore store;
+	store.slot[0] = primary_ray(U, pr);
+	uint64_t depths = queue_set_depth(SDFR_QUEUE_EMPTY, 0, 0);
+	int count = 1;
+
+	float hdr = -1.f;
+	vec3 acc = V3s(0.f);
+	for (int bounce = 0; bounce < U.bounce_count && count > 0; ++bounce)
+	{
+		cnt.rays++;
+		const int idx = queue_next(depths, U.ray_count);
+		const RayRec ray = store.slot[idx];
+		depths = queue_set_depth(depths, idx, RAY_DEPTH_INVALID);
+		--count;
+
+		const typename Scene::RayInv R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
+		const float inside_sign = ray_inside_sign(ray);
+		const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
+
+		March m = march_begin(ray.pos, ray.dir);
+		int status;
+		do
+		{
+			march_pre(m);
+			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
+			cnt.march_evals++;
+			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
+		} while (status == MARCH_CONTINUE);
+
+		vec3 out;
+		if (status == MARCH_HIT)
+		{
+			cnt.hits++;
+			HitInfo hit;
+			hit.pos = march_pos(m);
+			hit.t = m.t;
+			hit.d = m.d;
+			hit.iter = m.iter;
+			const float baseline = m.d * inside_sign;
+			float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+			float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+			float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+			hit.normal = normalize(V3(g0, g1, g2));
+
+			Spawner<LocalRayStore> q(store, depths, count, U.ray_count);
+			out = shade_hit<Scene, DBG, LocalRayStore>(U, F, ray, pr, hit, max_range, hdr, q);
+			depths = q.depths;
+			count = q.count;
+		}
+		else
+		{
+			out = shade_miss<Scene>(U, ray, m.iter);
+		}
+		acc = acc + out;
+	}
+	return V4(acc.x, acc.y, acc.z, abs1(hdr));
+}
+
+// scene registry: X(index, SceneType)
+#define SDFR_FOR_EACH_SCENE(X) \
+	X(0, SceneFastSphere) X(1, SceneCubeSea) X(2, SceneLabyrinth) X(3, SceneFractal) X(4, SceneLense) X(5, SceneGems) X(6, SceneLightShadows)
+enum { SDFR_SCENE_COUNT = 7 };
+
+} // namespace sdfr

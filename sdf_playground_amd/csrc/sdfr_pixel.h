@@ -1,0 +1,476 @@
+// sdfr_pixel.h -- the stages of the per-pixel raymarch pipeline (device code,
+// host-compilable): primary-ray generation, the 8-slot cost-ordered ray queue, one
+// sphere-tracing step, the forward-difference normal, hit shading with secondary-ray
+// spawning, and miss shading.
+//
+// Behavioural contract = the reference's ps_main (Engine/shader/pshader_sdf.hlsl:260-639)
+// with its helpers map_geometry (:111-135), map_material (:137-162), grad (:164-177),
+// march_ray (:179-220), find_next_ray / find_free_ray (:222-246).  The kernels
+// (sdfr_kernels.hip) decide how these stages are scheduled on the machine.
+#pragma once
+#include "sdfr_frame.h"
+#include "sdfr_lib.h"
+
+namespace sdfr {
+
+// ---- pixel -> primary ray (pshader_sdf.hlsl:263-267; pixel centres as D3D rasterises the
+// full-screen quad of FullscreenQuad.cpp:52-58, row 0 = top) -------------------------------
+struct PixelRay
+{
+	vec3 dir;
+	vec3 right_ray, bottom_ray; // footprint of one pixel per unit distance
+};
+SDF_HD PixelRay pixel_ray(const FrameU &U, int px, int py)
+{
+	float sx = ((float)px + 0.5f) / (float)U.width * 2.f - 1.f;
+	float sy = 1.f - ((float)py + 0.5f) / (float)U.height * 2.f;
+	vec3 d = U.front + sx * U.right + sy * U.top;
+	float invlen = 1.f / length(d);
+	PixelRay r;
+	r.dir = d * invlen;
+	r.right_ray = U.ddx * U.right * invlen;
+	r.bottom_ray = U.ddy * U.top * invlen;
+	return r;
+}
+SDF_HD RayRec primary_ray(const FrameU &U, const PixelRay &pr)
+{
+	RayRec r;
+	r.pos = U.eye;
+	r.dir = pr.dir;
+	r.contrib = V3(1.f, 1.f, 1.f);
+	r.shadow_range = 0.f;
+	r.bits = 0; // depth 0, outside, no transparency, not a shadow ray
+	return r;
+}
+SDF_HD RayFlags ray_flags(const RayRec &r)
+{
+	RayFlags f;
+	f.has_transparent = ray_has_transparent(r);
+	f.is_shadow = ray_is_shadow(r);
+	f.last_transparent_pos = f.has_transparent ? r.pos : V3s(0.f);
+	return f;
+}
+
+// ---- cost-ordered ray queue: depths packed one byte per slot ---------------------------------
+// find_next_ray (pshader_sdf.hlsl:222-233): smallest depth, lowest slot wins ties.
+SDF_HD int queue_next(uint64_t depths, int slots)
+{
+	int best = 0;
+	uint32_t best_depth = (uint32_t)(depths & 0xffu);
+	for (int i = 1; i < slots; ++i)
+	{
+		uint32_t d = (uint32_t)((depths >> (8 * i)) & 0xffu);
+		if (d < best_depth) { best = i; best_depth = d; }
+	}
+	return best;
+}
+// find_free_ray (pshader_sdf.hlsl:235-246): first invalid slot
+SDF_HD int queue_free(uint64_t depths, int slots)
+{
+	int i = 0;
+	for (; i < slots; ++i)
+		if (((depths >> (8 * i)) & 0xffu) == RAY_DEPTH_INVALID) break;
+	return i;
+}
+SDF_HD uint64_t queue_set_depth(uint64_t depths, int slot, uint32_t d)
+{
+	return (depths & ~(0xffull << (8 * slot))) | ((uint64_t)d << (8 * slot));
+}
+#define SDFR_QUEUE_EMPTY 0xffffffffffffffffull
+
+// ---- the driver's debug switches (pshader_sdf.hlsl:86-109) -----------------------------------
+// The kernels are specialised at compile time on DBG = "debug plane on or objects hidden";
+// the common case (DBG = false) carries no trace of them.  In the DBG = true build the two
+// wave-uniform switches are deliberately held in VGPRs (debug_flags), so every branch on them
+// is an ordinary exec-masked branch.  Reason (found on gfx950 / ROCm 7.2, see DESIGN.md
+// "Compiler hazard"): hipcc may materialise a wave-uniform bool through VALU under a partial
+// exec mask inside the divergent march loop and test it again after the loop under a wider
+// mask, where the lanes that left the loop early read stale zero bits.
+struct DebugFlags
+{
+	int plane_on; // any(debug normal)
+	int show_on;  // any(show_objects)
+};
+SDF_HD DebugFlags debug_flags(const FrameU &U)
+{
+	DebugFlags f;
+	f.plane_on = U.debug_plane_on;
+	f.show_on = U.show_on;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+v"(f.plane_on), "+v"(f.show_on));
+#endif
+	return f;
+}
+SDF_HD bool frame_needs_debug(const FrameU &U) { return U.debug_plane_on != 0 || U.show_on == 0; }
+
+// ---- scene distance with the driver's debug plane (pshader_sdf.hlsl:111-135) ---------------
+template <class Scene, bool DBG>
+SDF_HD float map_geometry(const FrameU &U, const DebugFlags &F, const typename Scene::RayInv &R, vec3 p, vec3 dir, bool fast)
+{
+	if (!DBG)
+		return Scene::dist(U, R, p, dir, fast);
+	float d = 3e38f;
+	if (F.show_on)
+		d = Scene::dist(U, R, p, dir, fast);
+	if (F.plane_on)
+	{
+		float plane = sd_plane_fast(p - V3(U.debug_x, U.debug_y, U.debug_z), dir, fast, U.debug_normal);
+		return min1(d, plane);
+	}
+	return d;
+}
+
+// ---- sphere tracing with over-relaxation (pshader_sdf.hlsl:179-220) as a resumable state ----
+struct March
+{
+	vec3 start, dir;
+	float t;          // camera_distance
+	float last_d;     // last_scene_distance
+	float last_safe;  // last_safe_camera_distance
+	float factor;     // step_factor
+	float d;          // scene_distance of the last evaluation (already * inside_sign)
+	uint32_t iter;
+};
+enum { MARCH_CONTINUE = 0, MARCH_HIT = 1, MARCH_MISS = 2 };
+
+SDF_HD March march_begin(vec3 start, vec3 dir)
+{
+	March m;
+	m.start = start;
+	m.dir = dir;
+	m.t = 0.f;
+	m.last_d = 0.f;
+	m.last_safe = 0.f;
+	m.factor = 1.f;
+	m.d = 0.f;
+	m.iter = 0;
+	return m;
+}
+SDF_HD vec3 march_pos(const March &m) { return mad(m.dir, m.t, m.start); }
+
+// consume one scene-distance sample `d` taken at march_pos(m); requires m.iter < iter_count
+SDF_HD int march_advance(March &m, float d, float dist_max, uint32_t iter_count)
+{
+	m.d = d;
+	if (m.factor > 1.f && (m.last_d + d) < m.last_d * m.factor)
+	{
+		// over-stepped: rewind to the last safe point and continue without relaxation
+		m.t = m.last_safe;
+		m.factor = 1.f;
+		m.iter++;
+		return m.iter < iter_count ? MARCH_CONTINUE : MARCH_MISS;
+	}
+	m.last_d = d;
+	if (m.t > dist_max) return MARCH_MISS;
+	if (d < SDFR_DIST_EPS) return MARCH_HIT;
+	m.last_safe = m.t + d;
+	m.t = m.t + d * m.factor;
+	m.iter++;
+	return m.iter < iter_count ? MARCH_CONTINUE : MARCH_MISS;
+}
+// relaxation starts at the fourth sample (pshader_sdf.hlsl:189-192)
+SDF_HD void march_pre(March &m) { if (m.iter == 3) m.factor = 1.5f; }
+
+// ---- forward-difference normal (pshader_sdf.hlsl:164-177, Q10) --------------------------------
+SDF_HD vec3 grad_sample_pos(vec3 p, int axis, float eps)
+{
+	if (axis == 0) return p + V3(eps, 0.f, 0.f);
+	if (axis == 1) return p + V3(0.f, eps, 0.f);
+	return p + V3(0.f, 0.f, eps);
+}
+
+// ---- results handed from marching to shading ---------------------------------------------------
+struct HitInfo
+{
+	vec3 pos;         // geometry_input.pos at the hit
+	float t;          // camera_distance
+	float d;          // scene_distance (* inside_sign)
+	uint32_t iter;
+	vec3 normal;      // normal_output.normal
+};
+
+// the queue storage is supplied by the caller (registers/scratch in the per-pixel kernel,
+// HBM arrays in the wavefront kernels)
+template <class Store>
+struct Spawner
+{
+	Store &store;
+	uint64_t depths;
+	int count;
+	int slots;
+	SDF_HD Spawner(Store &s, uint64_t d, int c, int n) : store(s), depths(d), count(c), slots(n) {}
+	// `if (ray_count < RAY_COUNT) { find_free_ray; fill; ++ray_count; }`
+	SDF_HD void push(const RayRec &r)
+	{
+		if (count < slots)
+		{
+			int slot = queue_free(depths, slots);
+			store.put(slot, r);
+			depths = queue_set_depth(depths, slot, ray_depth(r));
+			++count;
+		}
+	}
+};
+
+SDF_HD Material default_material(const FrameU &U, vec3 hit_pos)
+{
+	Material m;
+	m.id = MAT_NONE;
+	m.mpos = hit_pos;
+	m.prop_x = 0.f;
+	m.diffuse = V4(0.f, 0.f, 0.f, 1.f);
+	m.specular = V4(0.f, 0.f, 0.f, 60.f);
+	m.emissive = V3s(0.f);
+	m.reflection = V3s(0.f);
+	m.refraction = V3s(0.f);
+	m.ior = 1.4f;
+	m.normal = V4(0.f, 0.f, 0.f, 0.f);
+	m.max_cost = U.max_cost_default;
+	m.use_hdr = true;
+	return m;
+}
+
+// map_material (pshader_sdf.hlsl:137-162)
+template <class Scene, bool DBG>
+SDF_HD void map_material(const FrameU &U, const DebugFlags &F, const SurfacePoint &sp, Material &m)
+{
+	if (!DBG)
+	{
+		Scene::material(U, sp, m);
+		return;
+	}
+	bool on_debug_plane = false;
+	if (F.plane_on)
+	{
+		float plane = sd_plane(sp.pos - V3(U.debug_x, U.debug_y, U.debug_z), U.debug_normal);
+		on_debug_plane = on_surface(plane);
+	}
+	if (on_debug_plane)
+	{
+		RayFlags nf;
+		nf.has_transparent = false;
+		nf.is_shadow = false;
+		nf.last_transparent_pos = V3s(0.f);
+		typename Scene::RayInv R0 = Scene::ray_setup(U, sp.dir, nf);
+		float d = Scene::dist(U, R0, sp.pos, sp.dir, false);
+		m.id = MAT_DISTANCE_PLANE;
+		m.prop_x = d / U.debug_scale;
+	}
+	else
+	{
+		Scene::material(U, sp, m);
+	}
+}
+
+// Shade a ray that hit the scene (pshader_sdf.hlsl:317-620).  Returns the colour this ray
+// adds to the pixel (already multiplied by the ray's contribution); updates `hdr`; pushes
+// secondary rays.
+template <class Scene, bool DBG, class Store>
+SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, const PixelRay &px, const HitInfo &hit, float max_range,
+	float &hdr, Spawner<Store> &q)
+{
+	const uint32_t depth = ray_depth(ray);
+	const float inside_sign = ray_inside_sign(ray);
+	const vec3 view_dir = ray.dir;
+
+	SurfacePoint sp;
+	sp.pos = hit.pos;
+	sp.dir = ray.dir;
+	sp.camera_distance = hit.t;
+	sp.right_off = px.right_ray;
+	sp.bottom_off = px.bottom_ray;
+
+	Material m = default_material(U, hit.pos);
+	map_material<Scene, DBG>(U, F, sp, m);
+
+	vec3 out = V3s(0.f);
+	if (!ray_is_shadow(ray))
+	{
+		// the first surface decides whether the pixel is tone-mapped (Q2)
+		float new_hdr = m.use_hdr ? 1.f : 0.f;
+		hdr = lerp1(hdr, new_hdr, step1(hdr, 0.f));
+
+		vec3 n = lerp(hit.normal, V3(m.normal.x, m.normal.y, m.normal.z), m.normal.w);
+
+		// reflection: cost 3, outside rays only
+		if (any3(m.reflection) && inside_sign > 0.f && depth + 3 < m.max_cost)
+		{
+			vec3 rv = reflect(view_dir, n);
+			RayRec c;
+			c.pos = mad(rv, SDFR_REFLECT_EPS, hit.pos);
+			c.dir = rv;
+			c.contrib = m.reflection * ray.contrib;
+			c.shadow_range = 0.f;
+			c.bits = depth + 3;
+			q.push(c);
+		}
+		// refraction: admitted at cost 4, queued at cost 2 (pshader_sdf.hlsl:387,405)
+		if (any3(m.refraction) && depth + 4 < m.max_cost)
+		{
+			RayRec c;
+			vec3 rv;
+			if (inside_sign > 0.f)
+			{
+				rv = refract(view_dir, n, 1.f / m.ior);
+				c.bits = (depth + 2) | RAY_INSIDE;
+			}
+			else
+			{
+				rv = refract(view_dir, -n, m.ior);
+				c.bits = depth + 2;
+			}
+			c.pos = mad(rv, SDFR_REFRACT_EPS, hit.pos);
+			c.dir = rv;
+			c.contrib = m.refraction * ray.contrib;
+			c.shadow_range = 0.f;
+			q.push(c);
+		}
+
+		vec3 diffuse = V3(m.diffuse.x, m.diffuse.y, m.diffuse.z);
+		vec3 color = V3s(0.f);
+		bool use_light = true;
+		switch (m.id)
+		{
+		case MAT_ITER:
+			color = color + mat_iter_heat(hit.iter, (uint32_t)(U.iter_count - 1));
+			use_light = false;
+			hdr = 0.f;
+			break;
+		case MAT_PLAIN:
+			color = color + diffuse;
+			use_light = false;
+			break;
+		case MAT_NORMAL1:
+		{
+			vec3 nc = max(n, 0.01f);
+			nc = nc / max1(max1(nc.x, nc.y), nc.z);
+			color = color + nc;
+			use_light = false;
+			hdr = 0.f;
+			break;
+		}
+		case MAT_NORMAL2:
+			color = color + abs(n);
+			use_light = false;
+			hdr = 0.f;
+			break;
+		case MAT_DISTANCE_PLANE:
+			color = color + mat_debug_plane(m.prop_x);
+			use_light = false;
+			hdr = 0.f;
+			break;
+		case MAT_WOOD:
+			diffuse = diffuse + mat_wood(m.mpos);
+			break;
+		case MAT_MARBLE_DARK:
+			diffuse = diffuse + mat_marble(m.mpos, V3(0.556f, 0.478f, 0.541f));
+			break;
+		case MAT_MARBLE_LIGHT:
+			diffuse = diffuse + mat_marble(m.mpos, V3(0.7f, 0.7f, 0.7f));
+			break;
+		case MAT_FIRE:
+		{
+			float fadeout = sat1(dot(-view_dir, n));
+			vec4 fc = mat_fire(m.mpos, 1.f - fadeout);
+			color = color + V3(fc.x, fc.y, fc.z);
+			m.diffuse = V4(1.f, 1.f, 1.f, sat1(fc.w));
+			break;
+		}
+		default:
+			break;
+		}
+
+		// see-through surface: continue the same ray from the hit point (Q8)
+		if (m.diffuse.w < 1.f && depth + 2 < m.max_cost)
+		{
+			RayRec c;
+			c.pos = hit.pos;
+			c.dir = view_dir;
+			c.contrib = (1.f - m.diffuse.w) * V3(m.diffuse.x, m.diffuse.y, m.diffuse.z) * ray.contrib;
+			c.shadow_range = 0.f;
+			c.bits = (depth + 2) | RAY_TRANSPARENT;
+			q.push(c);
+		}
+
+		if (use_light)
+		{
+			const float ambient = 0.075f;
+			float move = max1(SDFR_SHADOW_EPS, SDFR_GRAD_EPS) + max1(0.f, -hit.d);
+			vec3 lit_pos = mad(n, move, hit.pos);
+			const float alpha = sat1(m.diffuse.w);
+
+			for (int i = 0; i < U.light_count; ++i)
+			{
+				Light L;
+				if (!Scene::light(U, i, L)) continue;
+				vec3 ldir;
+				float trace_dist;
+				float falloff = 1.f;
+				if (L.directional)
+				{
+					ldir = L.pos / (length(L.pos) + SDFR_DIST_EPS);
+					trace_dist = U.range;
+				}
+				else
+				{
+					ldir = lit_pos - L.pos;
+					trace_dist = length(ldir);
+					ldir = ldir / trace_dist;
+					trace_dist = trace_dist - L.extend;
+					falloff = pow1(0.1f, L.falloff); // distance-independent (Q3)
+				}
+				vec3 lcol = L.color * falloff;
+
+				color = color + diffuse * lcol * ambient;
+
+				// diffuse + Blinn specular are delivered by the shadow ray if it escapes (F6)
+				float ndl = sat1(dot(-n, ldir));
+				vec3 direct = V3s(0.f) + diffuse * lcol * ndl;
+				vec3 half_vec = -normalize(view_dir + ldir);
+				float spec = pow1(sat1(dot(n, half_vec)), m.specular.w);
+				direct = direct + V3(m.specular.x, m.specular.y, m.specular.z) * lcol * spec;
+
+				if (depth + 2 < m.max_cost && ndl > 0.f)
+				{
+					RayRec c;
+					c.pos = lit_pos;
+					c.dir = -ldir;
+					c.contrib = direct * ray.contrib * alpha;
+					c.shadow_range = trace_dist;
+					c.bits = (depth + 2) | RAY_SHADOW;
+					q.push(c);
+				}
+			}
+			color = color + m.emissive;
+			color = color * alpha;
+		}
+		out = out + color * ray.contrib;
+	}
+	else
+	{
+		// a shadow ray stopped by a see-through surface continues, tinted (pshader_sdf.hlsl:598-619)
+		if (m.diffuse.w < 1.f && depth + 2 < m.max_cost)
+		{
+			RayRec c;
+			c.pos = hit.pos;
+			c.dir = view_dir;
+			c.contrib = (1.f - m.diffuse.w) * V3(m.diffuse.x, m.diffuse.y, m.diffuse.z) * ray.contrib;
+			c.shadow_range = max_range - hit.t;
+			c.bits = (depth + 2) | RAY_TRANSPARENT | RAY_SHADOW;
+			q.push(c);
+		}
+	}
+	return out;
+}
+
+// A ray that left the scene (pshader_sdf.hlsl:621-632): an escaped shadow ray delivers the
+// light it carries, any other ray sees the background.
+template <class Scene>
+SDF_HD vec3 shade_miss(const FrameU &U, const RayRec &ray, uint32_t iter)
+{
+	if (ray_is_shadow(ray))
+		return V3s(0.f) + ray.contrib;
+	return V3s(0.f) + Scene::background(U, ray.dir, iter) * ray.contrib;
+}
+
+} // namespace sdfr

@@ -1,0 +1,580 @@
+// sdfr_scenes.h -- ahead-of-time scene functors (device code, host-compilable).
+//
+// The reference compiles a scene INTO its pixel shader by textual substitution of
+// "sdf_scene.hlsl" (pshader_sdf.hlsl:84, Application.cpp:229,320); here each scene is a
+// functor instantiated into the kernel templates.  The scene plugin ABI of the reference --
+// map / map_normal / map_light / map_background (README.md:114-119) -- maps to:
+//   prepare()     host, once per frame: frame-uniform constants (sin/cos of stime, ...)
+//   ray_setup()   once per ray: everything in map() that depends on the ray only
+//   dist()        map(..., geometry_step = true): scene distance at a point
+//   material()    map(..., geometry_step = false): material of the surface at a hit point
+//   use_normal()  map_normal (no config scene provides one)
+//   light()       map_light, one light slot at a time
+//   background()  map_background
+//
+// Scenes: fast_sphere, cube_sea, labyrinth, fractal, lense, gems, light_shadows
+// (Engine/shader/scenes/sdf_scene_<name>.hlsl).
+#pragma once
+#include "sdfr_frame.h"
+#include "sdfr_lib.h"
+
+namespace sdfr {
+
+// Ray-dependent part of the shared checker floor (sdf_common.hlsl:62-83 via
+// sdf_primitives.hlsl:59-70): the fast plane divides by saturate(dot(dir, -n)) + 1e-20.
+SDF_HD float ground_denominator(vec3 dir) { return sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f; }
+SDF_HD float ground_dist(vec3 p, bool fast, float denom)
+{
+	float d = dot(p, V3(0.f, 1.f, 0.f));
+	return fast ? d / denom : d;
+}
+SDF_HD void ground_material(const SurfacePoint &sp, Material &m)
+{
+	if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f))))
+	{
+		vec3 off_right = sp.right_off * sp.camera_distance;
+		vec3 off_bottom = sp.bottom_off * sp.camera_distance;
+		vec3 c = checker_color(sp.pos, sp.dir, off_right, off_bottom);
+		m.diffuse = V4(c.x, c.y, c.z, 1.f);
+		m.specular.x = m.specular.y = m.specular.z = 1.f;
+	}
+}
+// the single white directional light all config scenes but light_shadows use
+SDF_HD bool sun_light(int i, Light &L)
+{
+	if (i != 0) return false;
+	L.pos = V3(-1.f, -1.f, 2.f);
+	L.directional = true;
+	L.color = V3(1.f, 1.f, 1.f);
+	L.extend = 0.f;
+	L.falloff = 0.f;
+	return true;
+}
+SDF_HD void set_rgb(vec4 &c, float v) { c.x = v; c.y = v; c.z = v; }
+
+// =========================================================================================
+struct SceneFastSphere
+{
+	static const char *name() { return "fast_sphere"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { float ground_denom; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		return r;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3 dir, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		return min1(d, sd_sphere_fast(p - V3(0.f, 1.f, 0.f), dir, fast, 0.5f));
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(sd_sphere(sp.pos - V3(0.f, 1.f, 0.f), 0.5f)))
+		{
+			m.diffuse = V4(0.2f, 0.7f, 0.2f, 1.f);
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneCubeSea
+{
+	static const char *name() { return "cube_sea"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { float ground_denom; vec2 barrier; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		// cell-wall guard (sdf_primitives.hlsl:118-124): which wall the ray runs towards
+		r.barrier = (V2(step1(0.f, dir.x), step1(0.f, dir.z)) - 0.5f) * V2(2.01f, 2.01f);
+		return r;
+	}
+	struct Cell { vec3 cell_pos; float cube; bool is_other; };
+	static SDF_HD Cell eval_cell(const FrameU &U, vec3 p)
+	{
+		Cell c;
+		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(2.f, 2.f));
+		c.cell_pos = V3(rep.x, p.y, rep.y);
+		vec2 cell_index = (V2(p.x, p.z) - rep) / 2.f;
+		vec2 q = cell_index * 0.5f + 0.25f;
+		vec2 sometimes = V2(rne1(frac1(q.x)), rne1(frac1(q.y)));
+		c.is_other = sometimes.x < 0.5f && sometimes.y < 0.5f;
+		float phase = cell_index.x + cell_index.y * 0.3f + U.stime;
+		vec2 sc = sincos1(phase);
+		vec2 r = op_rotate(rep, sc.y * 0.4f);
+		vec3 cube_pos = V3(r.x, p.y, r.y);
+		float hs = c.is_other ? 0.25f : 0.5f;
+		c.cube = sd_box(cube_pos - V3(0.f, 2.f + sc.x, 0.f), V3s(hs)) - 0.15f;
+		return c;
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		Cell c = eval_cell(U, p);
+		d = min1(d, c.cube);
+		vec2 t = (R.barrier - V2(c.cell_pos.x, c.cell_pos.z)) / V2(dir.x, dir.z);
+		return min1(d, min1(t.x, t.y));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		Cell c = eval_cell(U, sp.pos);
+		if (on_surface(c.cube))
+		{
+			if (c.is_other)
+			{
+				m.diffuse = V4(0.8f, 0.2f, 0.2f, 1.f);
+				set_rgb(m.specular, 1.f);
+			}
+			else
+			{
+				m.diffuse = V4(0.6f, 0.5f, 0.2f, 1.f);
+				set_rgb(m.specular, 1.f);
+				m.reflection = V3s(0.25f);
+			}
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneLabyrinth
+{
+	static const char *name() { return "labyrinth"; }
+	static const char *variables() { return ""; }
+	enum { SU_FIRE_SCROLL = 0 };
+	static void prepare(FrameU &U) { U.su[SU_FIRE_SCROLL] = U.stime * 3.f; }
+
+	static SDF_HD float fire_cone(vec3 p) { return sd_round_cone(p, V3(0.f, 1.1f, 0.f), V3(0.f, 1.6f, 0.f), 0.15f, 0.1f); }
+
+	struct RayInv { float ground_denom; bool skip_fire; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		// a ray continuing through a transparent surface ignores the fire it just left
+		// (OBJECT_TRANSPARENT, pshader_sdf.hlsl:80; sdf_scene_labyrinth.hlsl:55,62)
+		r.skip_fire = f.has_transparent && fire_cone(f.last_transparent_pos) < SDFR_DIST_EPS;
+		return r;
+	}
+
+	static SDF_HD float vase(vec3 p)
+	{
+		float bowl = sd_sphere(p - V3(0.f, 1.89f, 0.f), 0.5f);
+		float stem = sd_capped_cylinder(p - V3(0.f, 0.8f, 0.f), 0.75f, 0.2f);
+		float foot = sd_box(p - V3(0.f, 0.075f, 0.f), V3(0.4f, 0.075f, 0.4f));
+		float cut_top = sd_plane(p - V3(0.f, 1.9f, 0.f), V3(0.f, 1.f, 0.f));
+		float cut_low = sd_plane(p - V3(0.f, 1.5f, 0.f), V3(0.f, -1.f, 0.f));
+		float d = max1(bowl, cut_low);
+		d = op_pipe_merge(d, stem, 0.1f, 4.f);
+		d = op_pipe_merge(d, foot, 0.1f, 4.f);
+		d = max1(d, cut_top);
+		d = max1(d, -bowl - 0.06f);
+		return d;
+	}
+
+	struct Objects { float wall, vase, wood, fire; vec3 torch_pos; };
+	static SDF_HD Objects eval_objects(vec3 p)
+	{
+		Objects o;
+		// 20 x 20 cells, mirrored into one octant
+		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(20.f, 20.f));
+		float wx = abs1(rep.x), wz = abs1(rep.y);
+		if (wz > wx) { float t = wx; wx = wz; wz = t; }
+		vec3 wp = V3(wx, p.y, wz);
+
+		float wall1 = sd_box(wp - V3(3.5f, 2.f, 3.f), V3(1.5f, 2.f, 1.f));
+		float wall2 = sd_box(wp - V3(7.f, 2.f, 5.f), V3(3.f, 2.f, 1.f));
+		o.wall = min1(wall1, wall2);
+
+		vec3 vp = wp;
+		vp.x = abs1(vp.x - 8.f);
+		o.vase = vase(vp - V3(1.f, 0.f, 3.f));
+
+		// torch: a tilted wooden stick with a flame cone
+		const float torch_angle = 15.f * SDFR_PI / 180.f;
+		const float tc = cos1(torch_angle), ts = sin1(torch_angle);
+		vec3 tp = wp - V3(5.f, 2.f, 3.f);
+		vec3 sp = V3(tp.x * tc - tp.y * ts, tp.x * ts + tp.y * tc, tp.z);
+		tp.x = tp.x - 0.3f;
+		o.wood = sd_box(sp - V3(0.f, 0.6f, 0.f), V3(0.05f, 0.5f, 0.05f));
+		o.fire = fire_cone(tp);
+		o.torch_pos = tp;
+		return o;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		Objects o = eval_objects(p);
+		d = min1(d, o.wall);
+		d = min1(d, o.vase);
+		d = min1(d, o.wood);
+		return R.skip_fire ? d : min1(d, o.fire);
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		Objects o = eval_objects(sp.pos);
+		if (on_surface(o.wall))
+		{
+			m.mpos = sp.pos;
+			m.id = MAT_MARBLE_LIGHT;
+		}
+		else if (on_surface(o.vase))
+		{
+			m.mpos = sp.pos * 3.f;
+			m.id = MAT_MARBLE_DARK;
+		}
+		else if (on_surface(o.wood))
+		{
+			m.mpos = V3(sp.pos.x, sp.pos.z, sp.pos.y) * 2.f;
+			m.id = MAT_WOOD;
+		}
+		else if (on_surface(o.fire))
+		{
+			m.mpos = o.torch_pos * 3.f - V3(0.f, U.su[SU_FIRE_SCROLL], 0.f);
+			m.id = MAT_FIRE;
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneFractal
+{
+	static const char *name() { return "fractal"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { float ground_denom; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		return r;
+	}
+	// order (a, b, c) so that a >= b >= c, as three compare-exchanges
+	static SDF_HD void sort3_desc(float &a, float &b, float &c)
+	{
+		float t;
+		if (c > b) { t = b; b = c; c = t; }
+		if (b > a) { t = a; a = b; b = t; }
+		if (c > b) { t = b; b = c; c = t; }
+	}
+	// 8-level recursive fold; returns the distance, and the level that first touched
+	static SDF_HD float fold(vec3 p, float *level_hit)
+	{
+		const float size = 1.f;
+		vec3 q = p - V3(0.f, 1.f, 0.f);
+		float d = 1e30f;
+		float scale = 1.f;
+		float hit_level = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+		{
+			float nd = sd_box(q, V3s(size * 0.5f)) / scale;
+			if (nd < 0.0001f && d > 0.0001f) hit_level = (float)i;
+			d = min1(d, nd);
+			q = abs(q);
+			sort3_desc(q.y, q.x, q.z);
+			q.y = q.y - size * 2.f / 3.f;
+			q.y = q.y + size / 3.f;
+			sort3_desc(q.y, q.x, q.z);
+			q.y = q.y - size / 3.f;
+			q = q * 3.f;
+			scale = scale * 3.f;
+		}
+		*level_hit = hit_level;
+		return d;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float lvl;
+		return min1(d, fold(p, &lvl));
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		float lvl;
+		float d = fold(sp.pos, &lvl);
+		if (on_surface(d))
+		{
+			m.diffuse.x = 0.9f;
+			m.diffuse.y = 0.7f;
+			m.diffuse.z = lvl * 0.125f;
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneLense
+{
+	static const char *name() { return "lense"; }
+	// the scene's VAR_ tags in source order; slot k of FrameU::scene_var is the k-th distinct name
+	static const char *variables()
+	{
+		return "VAR_xpos(min = -4, max = 4, step = 0.1) VAR_ypos(min = -4, max = 4, step = 0.1) "
+			   "VAR_zpos(min = 0, max = 25, step = 0.1) VAR_mixing(min = 0, max = 1, step = 0.05)";
+	}
+	enum { VAR_XPOS = 0, VAR_YPOS = 1, VAR_ZPOS = 2, VAR_MIXING = 3 };
+	enum { SU_MIRROR_S = 0, SU_MIRROR_C = 1 };
+	static void prepare(FrameU &U)
+	{
+		vec2 sc = sincos1(U.stime * 0.3f);
+		U.su[SU_MIRROR_S] = sc.x;
+		U.su[SU_MIRROR_C] = sc.y;
+	}
+	struct RayInv { int unused; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
+
+	struct Objects { float bg1, bg2, lense, sphere, mirror, frame; vec3 mirror_pos; vec2 bg1_xz; };
+	static SDF_HD float blob(vec3 p)
+	{
+		return lerp1(sd_sphere(p, 1.f), sd_box(p, V3s(1.f)), 0.65f) - 0.1f;
+	}
+	static SDF_HD Objects eval_objects(const FrameU &U, vec3 p)
+	{
+		Objects o;
+		vec3 b1 = p - V3(0.f, -5.f, 0.f);
+		vec2 r1 = op_rep_inf(V2(b1.x, b1.z), V2(3.f, 3.f));
+		o.bg1_xz = r1;
+		o.bg1 = blob(V3(r1.x, b1.y, r1.y));
+
+		vec3 b2 = p - V3(0.f, 5.f, 0.f);
+		vec2 r2 = op_rep_inf(V2(b2.x, b2.z), V2(10.f, 10.f));
+		o.bg2 = blob(V3(r2.x, b2.y, r2.y));
+
+		vec3 lp = abs(p);
+		lp.z = lp.z - 5.1f;
+		o.lense = max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f));
+
+		o.sphere = sd_sphere(p - V3(U.scene_var[VAR_XPOS], U.scene_var[VAR_YPOS], U.scene_var[VAR_ZPOS]), 2.f);
+
+		vec3 mp = p - V3(0.f, 0.f, -5.f);
+		vec2 mr = rot2(V2(mp.x, mp.z), U.su[SU_MIRROR_S], U.su[SU_MIRROR_C]);
+		mp = V3(mr.x, mp.y, mr.y);
+		o.mirror_pos = mp;
+		o.mirror = sd_box(mp, V3(1.f, 2.f, 0.1f));
+		o.frame = sd_box(mp, V3(1.1f, 2.1f, 0.08f));
+		return o;
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool)
+	{
+		Objects o = eval_objects(U, p);
+		float d = min1(3e38f, o.bg1);
+		d = min1(d, o.bg2);
+		d = min1(d, o.lense);
+		d = min1(d, o.sphere);
+		d = min1(d, o.mirror);
+		return min1(d, o.frame);
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		Objects o = eval_objects(U, sp.pos);
+		vec2 cell_index = (V2(sp.pos.x, sp.pos.z) - o.bg1_xz) / 3.f;
+		if (on_surface(o.bg1))
+		{
+			vec2 a = cell_index * 0.3f;
+			vec3 c1 = V3(sin1(a.x) * 0.5f + 0.5f, sin1(a.y) * 0.5f + 0.5f, 1.f);
+			vec3 c2 = cell_index.x < 0.01f ? V3(0.f, 1.f, 0.f) : V3(0.f, 0.f, 1.f);
+			vec3 c = lerp(c1, c2, 0.25f);
+			m.diffuse = V4(c.x, c.y, c.z, 1.f);
+			set_rgb(m.specular, 1.f);
+			m.reflection = V3s(0.5f);
+		}
+		else if (on_surface(o.bg2))
+		{
+			m.diffuse = V4(1.f, 0.5f, 0.f, 1.f);
+			set_rgb(m.specular, 1.f);
+			m.reflection = V3s(0.5f);
+		}
+		else if (on_surface(o.lense))
+		{
+			m.diffuse = V4(0.3f, 0.3f, 0.3f, 1.f);
+			m.refraction = V3(0.9f, 0.9f, 0.9f);
+		}
+		else if (on_surface(o.sphere))
+		{
+			m.diffuse = V4(1.f, 0.2f, 0.2f, 1.f);
+			m.emissive = V3(8.f, 0.f, 0.f);
+			set_rgb(m.specular, 1.f);
+			m.reflection = V3s(0.25f);
+		}
+		else if (on_surface(o.mirror))
+		{
+			m.diffuse = V4(0.1f, 0.1f, 0.1f, 1.f);
+			float mix = U.scene_var[VAR_MIXING];
+			m.refraction = V3s(mix);
+			m.reflection = V3s(1.f - mix);
+		}
+		else if (on_surface(o.frame))
+		{
+			m.mpos = o.mirror_pos;
+			m.id = MAT_WOOD;
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	// the scene carries its own copy of the sky (sdf_scene_lense.hlsl:108-117), same arithmetic
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneGems
+{
+	static const char *name() { return "gems"; }
+	static const char *variables() { return ""; }
+	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
+	static void prepare(FrameU &U)
+	{
+		vec2 sc = sincos1(U.stime * 0.5f);
+		U.su[SU_ROT_S] = sc.x;
+		U.su[SU_ROT_C] = sc.y;
+	}
+	struct RayInv { float ground_denom; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		return r;
+	}
+	static SDF_HD float gems(const FrameU &U, vec3 p, float *ring_index)
+	{
+		vec2 xz = rot2(V2(p.x, p.z), U.su[SU_ROT_S], U.su[SU_ROT_C]);
+		*ring_index = op_rep_angle(&xz, 8.f);
+		vec3 q = V3(xz.x - 1.f, p.y - 1.f, xz.y);
+		vec2 qxz = V2(q.x, q.z);
+		op_rep_angle(&qxz, 8.f);
+		q = V3(qxz.x, q.y, qxz.y);
+		float plane1 = sd_plane(q - V3(0.1f, 0.1f, 0.f), V3(0.707f, 0.707f, 0.f));
+		float plane2 = sd_plane(q, V3(0.707f, -0.707f, 0.f));
+		float plane3 = sd_plane(q - V3(0.f, 0.13f, 0.f), V3(0.f, 1.f, 0.f));
+		return op_smax2(op_smax2(plane1, plane2, 0.001f), plane3, 0.001f);
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float idx;
+		return min1(d, gems(U, p, &idx));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		float idx;
+		if (on_surface(gems(U, sp.pos, &idx)))
+		{
+			bool ruby = frac1(idx * 0.5f + 0.25f) > 0.5f;
+			m.diffuse.x = 0.8f;
+			m.diffuse.y = ruby ? 0.1f : 0.7f;
+			m.diffuse.z = ruby ? 0.3f : 0.1f;
+			set_rgb(m.specular, 1.f);
+			m.refraction = V3s(0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneLightShadows
+{
+	static const char *name() { return "light_shadows"; }
+	static const char *variables() { return ""; }
+	// su layout: 5 x {x, y_geometry, z, y_light} then 5 x rgb (colour of sphere i)
+	enum { SU_SPHERES = 0, SU_COLORS = 20 };
+	static SDF_HD vec3 color_from_index(uint32_t index)
+	{
+		float h = (float)index / 5.f;
+		vec3 c = hsv_to_rgb(V3(h, 1.f, 1.f));
+		return c / rgb_to_brightness(c);
+	}
+	static void prepare(FrameU &U)
+	{
+		float time = U.stime * 0.25f;
+		for (uint32_t i = 0; i < 5; ++i)
+		{
+			time = time + SDFR_PI * 2.f / 5.f;
+			float cx = cos1(time * 1.f) * -5.f;
+			float c2 = cos1(time * 2.f);
+			float sz = sin1(time * 2.f) * 2.f;
+			U.su[SU_SPHERES + 4 * i + 0] = cx;
+			U.su[SU_SPHERES + 4 * i + 1] = (c2 * -0.5f + 0.5f) * 2.f + 1.f;
+			U.su[SU_SPHERES + 4 * i + 2] = sz;
+			U.su[SU_SPHERES + 4 * i + 3] = (c2 * -0.5f + 0.5f) * 2.f + 0.5f;
+			vec3 c = color_from_index(i);
+			U.su[SU_COLORS + 3 * i + 0] = c.x;
+			U.su[SU_COLORS + 3 * i + 1] = c.y;
+			U.su[SU_COLORS + 3 * i + 2] = c.z;
+		}
+	}
+	struct RayInv { float ground_denom; bool is_shadow; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	{
+		RayInv r;
+		r.ground_denom = ground_denominator(dir);
+		r.is_shadow = f.is_shadow;
+		return r;
+	}
+	static SDF_HD float cubes(vec3 p)
+	{
+		vec2 rep = op_rep_lim(V2(p.x, p.z), V2(2.f, 2.f), V2(3.f, 3.f));
+		return sd_box(V3(rep.x, p.y, rep.y) - V3(0.f, 1.f, 0.f), V3s(0.4f)) - 0.1f;
+	}
+	static SDF_HD float sphere(const FrameU &U, vec3 p, int i)
+	{
+		return sd_sphere(p - V3(U.su[SU_SPHERES + 4 * i], U.su[SU_SPHERES + 4 * i + 1], U.su[SU_SPHERES + 4 * i + 2]), 0.2f);
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		if (!R.is_shadow) // the light bulbs do not shadow their own light
+		{
+#pragma unroll
+			for (int i = 0; i < 5; ++i)
+				d = min1(d, sphere(U, p, i));
+		}
+		return min1(d, cubes(p));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+#pragma unroll
+		for (int i = 0; i < 5; ++i)
+		{
+			if (on_surface(sphere(U, sp.pos, i)))
+				m.emissive = V3(U.su[SU_COLORS + 3 * i], U.su[SU_COLORS + 3 * i + 1], U.su[SU_COLORS + 3 * i + 2]);
+		}
+		if (on_surface(cubes(sp.pos)))
+		{
+			set_rgb(m.diffuse, 0.65f);
+			set_rgb(m.specular, 0.75f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
+	{
+		if (i < 1 || i > 5) return false;
+		int k = i - 1;
+		L.pos = V3(U.su[SU_SPHERES + 4 * k], U.su[SU_SPHERES + 4 * k + 3], U.su[SU_SPHERES + 4 * k + 2]);
+		L.directional = false;
+		L.extend = 0.25f;
+		L.falloff = 0.25f;
+		L.color = V3(U.su[SU_COLORS + 3 * k], U.su[SU_COLORS + 3 * k + 1], U.su[SU_COLORS + 3 * k + 2]) * 0.5f;
+		return true;
+	}
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+} // namespace sdfr

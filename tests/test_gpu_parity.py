@@ -1,0 +1,210 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (libsdfr.so), against the CPU
+oracle on identical camera / scene / variable inputs.
+
+Bar (BASELINE.json north_star): <= 1e-4 per-channel L-infinity on the fp32 RGBA frame.
+Because oracle and kernels share one arithmetic contract the frames are expected to be
+bit-identical; the tests assert the stated tolerance and additionally require bit equality
+of the per-pixel ray / march-evaluation / hit counters."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+W, H = 240, 160
+TH = 0.3
+
+
+def _cameras(oracle):
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    asp = np.float32(W) / np.float32(H)
+    return {
+        "fast_sphere": ("lookat", (0, 2, -3), (0, 1, 0)),
+        "cube_sea": ("dir", (3 * math.cos(TH), 4.5, 3 * math.sin(TH)), (math.cos(TH + 0.6), -0.45, math.sin(TH + 0.6))),
+        "labyrinth": ("dir", (1.5 * math.cos(TH), 5.0, 1.5 * math.sin(TH)), (math.cos(TH), -0.35, math.sin(TH))),
+        "fractal": ("lookat", (2.2 * math.cos(TH), 1.6, 2.2 * math.sin(TH)), (0, 1, 0)),
+        "lense": ("lookat", (7 * math.sin(-0.3), 0.5, 7 * math.cos(-0.3)), (0, 0, 0)),
+        "gems": ("lookat", (2.5 * math.cos(TH), 2, 2.5 * math.sin(TH)), (0, 1, 0)),
+        "light_shadows": ("lookat", (0, 5, -9), (0, 1, 0)),
+    }, fovy, asp
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    yield r
+    r.close()
+
+
+def _setup(renderer, oracle, scene, stime, limits=None, variables=None):
+    import sdf_playground_amd as sp
+
+    cams, fovy, asp = _cameras(oracle)
+    kind, eye, tgt = cams[scene]
+    basis = (oracle.camera_lookat if kind == "lookat" else oracle.camera_direction)(eye, tgt, fovy, asp)
+    f = oracle.default_frame(scene, W, H, basis=basis, stime=stime)
+    renderer.initShader(scene)
+    renderer.setParameters(stime)
+    cam = sp.Camera()
+    cam.SetEye(eye)
+    (cam.SetLookat if kind == "lookat" else cam.SetDirection)(tgt)
+    cam.SetFOVY(float(fovy))
+    cam.SetAspect(float(asp))
+    renderer.setCamera(cam)
+    # the C++ host camera must reproduce the oracle's (and the reference's) basis bit for bit
+    assert np.array_equal(renderer.getCameraBasis().view(np.uint32), basis.view(np.uint32))
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7)
+    if limits:
+        renderer.setLimits(**limits)
+        for k, v in limits.items():
+            setattr(f, k, v)
+    if variables:
+        table = {r[0]: r for r in oracle.var_table(scene)}
+        for k, v in variables.items():
+            assert renderer.setValue(k, v)
+            slot = table[k][6]
+            if slot >= 0:
+                f.scene_var[slot] = v
+            else:
+                setattr(f, k, v)
+    return f
+
+
+def _compare(renderer, oracle, scene, f, schedule):
+    renderer.setSchedule(schedule)
+    img, st = renderer.render(None, W, H, pixel_stats=True)
+    ref, rst, tot = oracle.render(scene, f, stats=True)
+    assert not np.isnan(img).any()
+    diff = np.abs(img.astype(np.float64) - ref.astype(np.float64)).max()
+    assert diff <= TOL, "%s: L-inf %g" % (scene, diff)
+    assert np.array_equal(st, rst), "%s: per-pixel ray/eval/hit counters differ" % scene
+    s = renderer.getStats()
+    assert (s.pixels, s.rays, s.march_evals, s.hits) == tuple(int(x) for x in tot)
+    return np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+SCENES = ["fast_sphere", "cube_sea", "labyrinth", "fractal", "lense", "gems", "light_shadows"]
+
+
+@pytest.mark.parametrize("schedule", [0, 1], ids=["wavefront", "pixel"])
+@pytest.mark.parametrize("stime", [0.0, 1.25])
+@pytest.mark.parametrize("scene", SCENES)
+def test_scene_parity_reference_limits(renderer, oracle, scene, stime, schedule):
+    f = _setup(renderer, oracle, scene, stime)
+    assert _compare(renderer, oracle, scene, f, schedule), "within tolerance but not bit-identical"
+
+
+@pytest.mark.parametrize("scene,limits", [
+    ("fast_sphere", dict(iter_count=64, max_cost_default=2)),   # BASELINE config 1: no secondary rays
+    ("cube_sea", dict(iter_count=128, max_cost_default=6)),     # config 2: exactly one reflection bounce
+    ("labyrinth", dict(iter_count=256)),                         # config 3 (headline)
+    ("fractal", dict(iter_count=512)),                           # config 4
+    ("lense", dict(max_cost_default=9)),                         # config 5: recursion depth 4
+    ("light_shadows", dict(ray_count=4, bounce_count=6)),       # queue overflow / bounce budget (Q4)
+    ("gems", dict(light_count=0)),
+])
+def test_scene_parity_extension_limits(renderer, oracle, scene, limits):
+    f = _setup(renderer, oracle, scene, 0.5, limits=limits)
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, scene, f, schedule)
+
+
+def test_variables_and_debug_views(renderer, oracle):
+    # scene variables (lense) and the driver's debug plane / show_objects (pshader_sdf.hlsl:86-135)
+    f = _setup(renderer, oracle, "lense", 0.25, variables=dict(xpos=1.5, ypos=-0.5, zpos=9.0, mixing=0.8))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "lense", f, schedule)
+    f = _setup(renderer, oracle, "labyrinth", 0.25, variables=dict(debug_ny=1.0, debug_y=1.5, debug_scale=0.5))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "labyrinth", f, schedule)
+    f = _setup(renderer, oracle, "fractal", 0.0, variables=dict(show_objects=0.0, debug_nx=0.3, debug_ny=1.0, debug_y=0.2))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "fractal", f, schedule)
+    renderer.initShader("lense")  # reloading a scene resets its variables (Application.cpp:237)
+    assert renderer.getVariableMap()["mixing"].value == 0.5
+
+
+def test_fp16_target_and_device_output(renderer, oracle):
+    import torch
+    import sdf_playground_amd as sp
+
+    f = _setup(renderer, oracle, "cube_sea", 0.0)
+    ref, _, _ = oracle.render("cube_sea", f)
+    out32 = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    out16 = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+    renderer.setStream(torch.cuda.current_stream().cuda_stream)
+    renderer.render(None, W, H, out=out32)
+    renderer.render(None, W, H, out=out16, fmt=sp.RGBA16F)
+    renderer.sync()
+    assert np.array_equal(out32.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # the reference's render target is R16G16B16A16_FLOAT (Postprocessing.cpp:23): fp32 rounded to half
+    assert np.array_equal(out16.cpu().numpy().view(np.uint16), ref.astype(np.float16).view(np.uint16))
+    renderer.setStream(0)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 8), (65, 9), (250, 131)])
+def test_ragged_sizes(renderer, oracle, size):
+    w, h = size
+    renderer.initShader("fast_sphere")
+    renderer.setParameters(0.0)
+    import sdf_playground_amd as sp
+    cam = sp.Camera()
+    cam.SetAspect(float(np.float32(w) / np.float32(h)))
+    renderer.setCamera(cam)
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7)
+    f = oracle.default_frame("fast_sphere", w, h)
+    ref, _, _ = oracle.render("fast_sphere", f)
+    for schedule in (0, 1):
+        renderer.setSchedule(schedule)
+        img = renderer.render(None, w, h)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_strip_sharding_matches_full_frame(renderer, oracle, world):
+    import torch
+    import sdf_playground_amd as sp
+
+    w, h = 200, 83  # ragged last strip
+    f = _setup(renderer, oracle, "labyrinth", 0.75)
+    cam = sp.Camera()
+    renderer.setSchedule(0)
+    full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    renderer.render(None, w, h, out=full)
+    n = sp.strip_buffer_pixels(w, h, world)
+    assert n == sp.strip_buffer_pixels_host(w, h, world)
+    gathered = torch.empty((world, n, 4), dtype=torch.float32, device="cuda")
+    for rank in range(world):
+        renderer.renderStrips(w, h, rank, world, gathered[rank])
+    out = torch.empty_like(full)
+    renderer.assembleStrips(w, h, world, gathered, out)
+    renderer.sync()
+    assert torch.equal(out, full)
+    # the host statement of the layout (used by the CPU multi-rank tests) agrees
+    assert np.array_equal(sp.assemble_strips_host(w, h, world, gathered.cpu().numpy()), full.cpu().numpy())
+
+
+def test_error_behaviour(oracle):
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    with pytest.raises(sp.SdfrError) as e:
+        r.render(None, 16, 16)  # no scene: SDFRenderer::render returns false (SDFRenderer.cpp:70-73)
+    assert e.value.code == -4
+    with pytest.raises(sp.SdfrError) as e:
+        r.initShader("no_such_scene")
+    assert e.value.code == -2
+    r.initShader("lense")
+    assert r.setValue("does_not_exist", 1.0) is False  # ignored (ShaderUtil.cpp:234-240)
+    with pytest.raises(sp.SdfrError):
+        r.setLimits(ray_count=9)
+    names = list(r.getVariableMap().keys())
+    assert names == [row[0] for row in oracle.var_table("lense")]
+    for row in oracle.var_table("lense"):
+        v = r.getVariableMap()[row[0]]
+        assert (v.minval, v.maxval, v.start, v.step, v.value) == tuple(np.float32(x) for x in row[1:6])
+    r.close()
