@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], concretised in SURVEY.md 8(d) cfg 3): the `labyrinth`
+scene at 3840x2160, iter_count 256, reference cost rules, default variables, on the fixed-seed
+16-frame camera sweep  eye = (1.5 cos t, 5, 1.5 sin t), dir = (cos t, -0.35, sin t),
+t = 2 pi (k + u_k) / 16, u_k = pcg_hash(0x5DF00003 + k) / 4294967295, stime = k / 60.
+One "step" = one full frame through the hot path (step s renders sweep frame s % 16).
+Metric: Mrays/s, ray := one iteration of the reference's bounce loop (primary + secondary).
+
+N > 1 (launched by torch.distributed.run, one process per GPU): each frame is cut into 8-row
+strips dealt round-robin over the ranks (strong scaling: the frame is fixed), every rank
+renders its strips into a compact buffer, one RCCL gather per frame moves them to rank 0,
+which scatters them into the image.  value = rays of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import sdf_playground_amd as sp
+
+SCENE = "labyrinth"
+WIDTH, HEIGHT = 3840, 2160
+ITER_COUNT = 256
+SEED = 0x5DF00003
+SWEEP = 16
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md (spec)
+CENSUS_FILE = os.path.join(ROOT, "profiles", "census_r01.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r01.json")
+
+
+def pcg_hash(x):
+    """The reference's PCG hash (noise.hlsl:6-11), uint32 wrap-around."""
+    state = (x * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+def sweep_camera(k):
+    """(eye, direction, stime) of sweep frame k."""
+    u = pcg_hash((SEED + k) & 0xFFFFFFFF) / 4294967295.0
+    t = 2.0 * math.pi * (k + u) / SWEEP
+    return (1.5 * math.cos(t), 5.0, 1.5 * math.sin(t)), (math.cos(t), -0.35, math.sin(t)), k / 60.0
+
+
+def make_camera(k, width=WIDTH, height=HEIGHT):
+    eye, direction, stime = sweep_camera(k)
+    cam = sp.Camera()
+    cam.SetEye(eye)
+    cam.SetDirection(direction)
+    cam.SetFOVY(sp.to_radian(60.0))
+    cam.SetAspect(float(np.float32(width) / np.float32(height)))
+    return cam, stime
+
+
+def load_census():
+    """flops per ray of this workload, from the operation-counting oracle build (committed)."""
+    try:
+        with open(CENSUS_FILE) as fh:
+            return json.load(fh)["labyrinth_4k_iter256"]
+    except Exception:
+        return None
+
+
+def cpu_baseline(max_seconds=30.0):
+    """The CPU oracle (a port: the reference HLSL cannot run here) timed on the host cores on a
+    bounded sample of the same workload: sweep frames 0..3, every 4th pixel in x and y."""
+    from oracle import pyoracle as po
+
+    cores = os.cpu_count() or 1
+    step = 4
+    frames = 4
+    rays = 0
+    pixels = 0
+    t_total = 0.0
+    used = 0
+    for k in range(frames):
+        eye, direction, stime = sweep_camera(k)
+        basis = po.camera_direction(eye, direction, np.float32(sp.to_radian(60.0)), np.float32(WIDTH) / np.float32(HEIGHT))
+        f = po.default_frame(SCENE, WIDTH, HEIGHT, basis=basis, stime=stime)
+        f.iter_count = ITER_COUNT
+        t0 = time.perf_counter()
+        _, _, tot = po.render(SCENE, f, step=(step, step), nthreads=cores)
+        t_total += time.perf_counter() - t0
+        pixels += int(tot[0])
+        rays += int(tot[1])
+        used += 1
+        if t_total > max_seconds:
+            break
+    return {
+        "value": rays / t_total / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "oracle (scalar C++ restatement, g++ -O2 -ffp-contract=off), sweep frames 0..%d of the same 3840x2160 workload, every %dth pixel in x and y (%d pixels, %d rays, %.1f s)" % (used - 1, step, pixels, rays, t_total),
+        "ms_per_frame_equiv": t_total / used * step * step * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--schedule", default=os.environ.get("SDFR_SCHEDULE", "auto"), choices=["auto", "wavefront", "pixel"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    W, H = a.width, a.height
+
+    r = sp.SDFRenderer(local_rank)
+    r.initShader(SCENE)
+    r.setLimits(iter_count=ITER_COUNT)
+    schedule = {"auto": sp.SCHEDULE_PIXEL, "wavefront": sp.SCHEDULE_WAVEFRONT, "pixel": sp.SCHEDULE_PIXEL}[a.schedule]
+    r.setSchedule(schedule)
+    stream = torch.cuda.current_stream()
+    r.setStream(stream.cuda_stream)
+
+    if distributed:
+        n_local = sp.strip_buffer_pixels(W, H, world)
+        local = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+        gathered = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+        gathered_flat = torch.empty((world, n_local, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+    image = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+
+    def step(s):
+        cam, stime = make_camera(s % SWEEP, W, H)
+        r.setParameters(stime)
+        r.setCamera(cam)
+        if not distributed:
+            r.render(None, W, H, out=image)
+        else:
+            r.renderStrips(W, H, rank, world, local)
+            if rank == 0:
+                dist.gather(local, gather_list=list(gathered_flat.unbind(0)), dst=0)
+                r.assembleStrips(W, H, world, gathered_flat, image)
+            else:
+                dist.gather(local, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        step(s)
+    fence()
+    # rays are a property of the frames, independent of timing: count them outside the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        ev[s][0].record(stream)
+        step(s)
+        ev[s][1].record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # per-frame ray counts of this rank (exact, from the kernels' counters), outside the timing
+    rays_per_frame = []
+    kernel_ms = []
+    for k in range(min(SWEEP, a.steps)):
+        step(k)
+        st = r.getStats()
+        rays_per_frame.append(int(st.rays))
+        kernel_ms.append(st.ms_gpu)
+    my_rays = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(a.steps))
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays_t = torch.tensor([my_rays], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rays = float(rays_t.item())
+
+    if rank == 0:
+        census = load_census()
+        out = {
+            "metric": "Mrays/s (primary+secondary), labyrinth scene, 3840x2160",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "labyrinth %dx%d, iter_count %d, reference cost rules (max_cost 7, hard shadows), 16-frame fixed-seed camera sweep (seed 0x5DF00003), default variables" % (W, H, ITER_COUNT),
+                "schedule": "pixel" if schedule == sp.SCHEDULE_PIXEL else "wavefront",
+                "parallelism": "strips%d" % world if distributed else "single",
+                "rays_per_pixel": total_rays / a.steps / (W * H),
+            },
+        }
+        # roofline of the dominant kernel (the only kernel of the pixel schedule), N = 1 geometry
+        mean_kernel_ms = float(np.mean(kernel_ms))
+        mean_rays = float(np.mean(rays_per_frame))
+        if census:
+            flops_per_launch = census["flops_per_ray"] * mean_rays
+            achieved = flops_per_launch / (mean_kernel_ms * 1e-3) / 1e12
+            traffic = None
+            try:
+                with open(PMC_FILE) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            out["roofline"] = {
+                "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic,
+                "kernel_ms": mean_kernel_ms, "flops_per_ray": census["flops_per_ray"],
+                "note": "FP32 vector (VALU) issue bounds this path, not HBM or MFMA (SURVEY.md 8d); flops = oracle operation census",
+            }
+        bytes_per_launch = 16.0 * W * H / world
+        out["roofline_hbm"] = {
+            "bound": "hbm", "achieved": bytes_per_launch / (mean_kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": bytes_per_launch / (mean_kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "note": "algorithmic bytes = one 16-byte RGBA32F store per pixel; reported because the north star asks for it",
+        }
+        out["step_ms_event_median"] = float(np.median(step_ms))
+        if not distributed and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the bench line must still be printed
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -222,3 +222,16 @@ def tonemap_png(rgba, path):
 
     with open(path, "wb") as fh:
         fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def census(scene, frame, step=(1, 1), region=None):
+    """Operation census of the oracle (liboracle_census.so, -DORACLE_CENSUS): renders the
+    sample single-threaded and returns (rgba, totals[4], flops, transcendentals).
+    Counting rule: + - * / sqrt rsqrt min max compare select floor/round = 1,
+    fma = 2, each transcendental (sin cos atan2 exp2 log2) = 1, abs/neg = 0."""
+    L = lib(census=True)
+    L.orc_census_reset()
+    out, _, totals = render(scene, frame, region=region, step=step, nthreads=1, census=True)
+    c = np.zeros(2, np.uint64)
+    L.orc_census_get(c.ctypes.data_as(ctypes.c_void_p))
+    return out, totals, int(c[0]), int(c[1])

@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def load_library():
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
     L.sdfr_sync.argtypes = [vp]
     L.sdfr_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.sdfr_selftest_math.argtypes = [vp, ci, cf, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 
@@ -339,6 +340,12 @@ class SDFRenderer:
         self._check(self._L.sdfr_assemble_strips(self._h, width, height, world, ctypes.c_void_p(gathered.data_ptr()),
                                                  ctypes.c_void_p(out.data_ptr()), fmt))
         return out
+
+    def selftestMath(self, what, constant=1.0):
+        """Exhaustive GPU check of the fast exact sqrt (what=0) / constant division (what=1); returns mismatches."""
+        n = ctypes.c_uint64()
+        self._check(self._L.sdfr_selftest_math(self._h, int(what), float(constant), ctypes.byref(n)))
+        return int(n.value)
 
     def sync(self):
         self._check(self._L.sdfr_sync(self._h))

@@ -433,18 +433,18 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 		SDFR_HIP(hipMemsetAsync(d_out, 0, local_pixels * bpp, r->stream));
 
 	SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream));
-	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	hipError_t e;
+	const size_t tiles = (((size_t)width + 7) / 8) * (((size_t)rm.local_rows + 7) / 8);
+	rc = ensure_workspace(r, tiles * 64);
+	if (rc != SDFR_OK) return rc;
+	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->schedule == SDFR_SCHEDULE_PIXEL)
 	{
-		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->stream);
+		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream);
 		r->last_wavefront = false;
 	}
 	else
 	{
-		const size_t tiles = (((size_t)width + 7) / 8) * (((size_t)rm.local_rows + 7) / 8);
-		rc = ensure_workspace(r, tiles * 64);
-		if (rc != SDFR_OK) return rc;
 		e = launch_wavefront_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream, r->profiling ? r->ev_march : nullptr,
 			r->profiling ? r->ev_shade : nullptr, &r->last_rounds);
 		r->last_wavefront = true;
@@ -480,6 +480,24 @@ int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, con
 	SDFR_HIP(hipSetDevice(r->device));
 	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->stream);
 	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
+	return SDFR_OK;
+}
+
+int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches)
+{
+	if (!r || !mismatches || what < 0 || what > 2) return SDFR_ERR_INVALID_ARGUMENT;
+	if (what >= 1 && !(constant != 0.f && constant == constant)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad divisor");
+	SDFR_HIP(hipSetDevice(r->device));
+	unsigned long long *d = nullptr;
+	SDFR_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), r->stream);
+	if (e == hipSuccess) e = launch_selftest_math(what, constant, d, r->stream);
+	unsigned long long h = 0;
+	if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, r->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return hip_fail(r, e, "selftest");
+	*mismatches = h;
 	return SDFR_OK;
 }
 

@@ -41,13 +41,15 @@ struct WavefrontWorkspace
 };
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, hipStream_t stream);
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream);
 
 hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
 	int *n_rounds_out);
 
 hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream);
+
+hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream);
 
 int device_cu_count(int device);
 

@@ -7,11 +7,11 @@
 //      k_march  persistent waves; every lane sphere-traces ONE ray at a time and, when its ray
 //               ends (hit: plus the 3 forward-difference normal samples, taken in the same
 //               loop so the scene function stays convergent), goes idle; when a ballot shows
-//               enough idle lanes the wave refills them from its next chunk of the round's
+//               enough idle lanes the wave refills them from its current range of the round's
 //               ray list.  Ray records live in HBM as structure-of-arrays, so a refill reads
-//               consecutive addresses.  No atomics in the loop: wave w owns chunks
-//               w, w + NW, w + 2 NW, ... of 64 rays, which also samples the whole image
-//               uniformly per wave (load balance).
+//               consecutive addresses.  A wave claims ranges of 128 list entries from a
+//               per-round cursor (one atomic per range), so the load balances itself
+//               whatever the grid size and the real residency are.
 //      k_shade  one lane per finished ray: material, lighting, secondary-ray spawn into the
 //               pixel's 8-slot queue (HBM), pop of the pixel's next ray, append to the next
 //               round's list with ONE atomic per block.
@@ -34,6 +34,8 @@ namespace sdfr {
 #define SDFR_INVALID_PIXEL 0xffffffffu
 // refill a march wave once this many lanes are idle (or when all are)
 #define SDFR_REFILL_THRESHOLD 16
+// list entries a march wave claims per atomic
+#define SDFR_GRAB 128
 
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
@@ -120,39 +122,13 @@ __device__ __forceinline__ void block_add_totals(RenderTotals *totals, uint32_t 
 }
 
 // =================================================================================================
-// PIXEL schedule
-// =================================================================================================
-template <class Scene, bool DBG>
-__global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals)
-{
-	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
-	PixelCounters c = {0, 0, 0};
-	uint32_t npix = 0;
-	PixelCoord pc;
-	if (w < n_work && work_to_pixel(U, rm, w, pc))
-	{
-		vec4 v = render_pixel<Scene, DBG>(U, pc.px, pc.py, c);
-		store_pixel(out, format, pc.pid, v);
-		if (pixel_stats)
-		{
-			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;
-			pixel_stats[3 * (size_t)pc.pid + 1] = c.march_evals;
-			pixel_stats[3 * (size_t)pc.pid + 2] = c.hits;
-		}
-		npix = 1;
-	}
-	block_add_totals(totals, npix, c.rays, c.march_evals, c.hits);
-}
-
-// =================================================================================================
 // WAVEFRONT schedule
 // =================================================================================================
 // ray record field order in the SoA arrays
 enum { RF_PX = 0, RF_PY, RF_PZ, RF_DX, RF_DY, RF_DZ, RF_CX, RF_CY, RF_CZ, RF_RANGE, RF_BITS, RF_COUNT };
 // march result fields
 enum { RS_STATUS = 0, RS_T, RS_D, RS_NX, RS_NY, RS_NZ, RS_COUNT };
-// counters[]: [r] = size of round r's list (r = 0..16)
+// counters[]: [r] = size of round r's list (r = 0..16); [32 + r] = march cursor of round r
 enum { CNT_ROUND0 = 0 };
 
 __device__ __forceinline__ RayRec load_ray(const float *base, size_t cap, uint32_t pid)
@@ -180,6 +156,44 @@ __device__ __forceinline__ void store_ray(float *base, size_t cap, uint32_t pid,
 	base[RF_BITS * cap + pid] = __uint_as_float(r.bits);
 }
 
+// pending rays of one pixel in the HBM queue arrays: [slot][field][pixel], so that lanes
+// holding neighbouring pixels touch neighbouring addresses
+struct GlobalRayStore
+{
+	float *queue;
+	size_t cap;
+	uint32_t pid;
+	__device__ __forceinline__ void put(int slot, const RayRec &r) { store_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid, r); }
+	__device__ __forceinline__ RayRec get(int slot) const { return load_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid); }
+};
+
+// =================================================================================================
+// PIXEL schedule
+// =================================================================================================
+template <class Scene, bool DBG>
+__global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, float *ray_queue, size_t cap)
+{
+	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
+	PixelCounters c = {0, 0, 0};
+	uint32_t npix = 0;
+	PixelCoord pc;
+	if (w < n_work && work_to_pixel(U, rm, w, pc))
+	{
+		GlobalRayStore store = {ray_queue, cap, pc.pid};
+		vec4 v = render_pixel<Scene, DBG, GlobalRayStore>(U, pc.px, pc.py, c, store);
+		store_pixel(out, format, pc.pid, v);
+		if (pixel_stats)
+		{
+			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;
+			pixel_stats[3 * (size_t)pc.pid + 1] = c.march_evals;
+			pixel_stats[3 * (size_t)pc.pid + 2] = c.hits;
+		}
+		npix = 1;
+	}
+	block_add_totals(totals, npix, c.rays, c.march_evals, c.hits);
+}
+
 // ---- k_init: primary rays, empty queues, cleared accumulators, round-0 list ---------------------
 __global__ __launch_bounds__(SDFR_BLOCK) void k_init(FrameU U, RowMap rm, uint32_t n_work, WavefrontWorkspace ws, uint32_t *pixel_stats)
 {
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_init(FrameU U, RowMap rm, uint32
 	{
 		ws.counters[CNT_ROUND0] = n_work;
 		for (int r = 1; r <= 16; ++r) ws.counters[r] = 0;
+		for (int r = 0; r < 16; ++r) ws.counters[32 + r] = 0; // march cursors
 	}
 	if (w >= n_work) return;
 	PixelCoord pc;
@@ -219,17 +234,17 @@ enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_GRAD0 = 2, LANE_GRAD1 = 3, LANE_GRAD2
 
 template <class Scene, bool DBG>
 __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
-	const uint32_t *__restrict__ n_ptr, uint32_t *pixel_stats, RenderTotals *totals)
+	const uint32_t *__restrict__ n_ptr, uint32_t *cursor, uint32_t *pixel_stats, RenderTotals *totals)
 {
 	const uint32_t n = *n_ptr;
 	const size_t cap = ws.capacity;
 	const DebugFlags F = debug_flags(U);
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t nwaves = (gridDim.x * SDFR_BLOCK) >> 6;
-	uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * SDFR_BLOCK + threadIdx.x) >> 6);
-	// [next, end) = unconsumed part of this wave's current chunk of the list (wave-uniform)
-	uint32_t next = chunk * 64u;
-	uint32_t end = next + 64u < n ? next + 64u : n;
+	// [next, end) = unconsumed part of the list range this wave currently owns (wave-uniform).
+	// Ranges of SDFR_GRAB entries are claimed from a per-round cursor with one atomic each, so
+	// the load balances itself whatever the grid size and residency are.
+	uint32_t next = 0, end = 0;
+	bool exhausted = n == 0;
 
 	int state = LANE_IDLE;
 	uint32_t pid = 0;
@@ -244,9 +259,21 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 		const unsigned long long idle = __ballot(state == LANE_IDLE);
 		if (idle)
 		{
-			const bool more = next < n;
+			if (next == end && !exhausted)
+			{
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(cursor, (uint32_t)SDFR_GRAB);
+				base = __builtin_amdgcn_readfirstlane(base);
+				if (base >= n)
+					exhausted = true;
+				else
+				{
+					next = base;
+					end = base + SDFR_GRAB < n ? base + SDFR_GRAB : n;
+				}
+			}
 			const uint32_t n_idle = (uint32_t)__popcll(idle);
-			if (!more)
+			if (next == end)
 			{
 				if (n_idle == 64u) break; // list drained and every lane finished
 			}
@@ -273,15 +300,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 						}
 					}
 				}
-				const uint32_t taken = n_idle < avail ? n_idle : avail;
-				next += taken;
-				if (next == end)
-				{
-					chunk += nwaves;
-					next = chunk * 64u;
-					if (next > n) next = n;
-					end = next + 64u < n ? next + 64u : n;
-				}
+				next += n_idle < avail ? n_idle : avail;
 			}
 		}
 
@@ -344,14 +363,6 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 }
 
 // ---- k_shade -----------------------------------------------------------------------------------------
-struct GlobalRayStore
-{
-	float *queue;
-	size_t cap;
-	uint32_t pid;
-	__device__ __forceinline__ void put(int slot, const RayRec &r) { store_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid, r); }
-};
-
 template <class Scene, bool DBG>
 __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
 	const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ next_list, uint32_t *next_n, int round, void *out, int format,
@@ -462,6 +473,43 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, 
 	}
 }
 
+// ---- self-test of the fast exact arithmetic (sdfr_math.h: sqrt1, div_c) ------------------------------
+// what = 0: sqrt1(a) against the generic IEEE lowering for a = +0 and every a in [2^-96, FLT_MAX]
+// what = 1: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-100 <= |a| <= 2^100
+// what = 2: negative control -- the plain reciprocal multiply a * (1/c) on the same inputs (must differ)
+__global__ __launch_bounds__(SDFR_BLOCK) void k_selftest_math(int what, float c, unsigned long long *mismatches)
+{
+	const unsigned long long stride = (unsigned long long)gridDim.x * SDFR_BLOCK;
+	unsigned int bad = 0;
+	const float rc = 1.0f / c;
+	for (unsigned long long u = (unsigned long long)blockIdx.x * SDFR_BLOCK + threadIdx.x; u < (1ull << 32); u += stride)
+	{
+		const float a = __uint_as_float((uint32_t)u);
+		float ref, got;
+		if (what == 0)
+		{
+			if (!(a == 0.f && u == 0) && !(a >= 0x1p-96f && a <= 3.402823466e+38f)) continue;
+			ref = sqrt_ieee(a);
+			got = sqrt1(a);
+		}
+		else
+		{
+			const float m = abs1(a);
+			if (!(u == 0) && !(m >= 0x1p-100f && m <= 0x1p100f)) continue;
+			ref = a / c;
+			got = what == 1 ? div_c(a, c, rc) : a * rc;
+		}
+		if (__float_as_uint(ref) != __float_as_uint(got)) bad++;
+	}
+	if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_selftest_math, dim3(8192), dim3(SDFR_BLOCK), 0, stream, what, c, d_mismatches);
+	return hipGetLastError();
+}
+
 // =================================================================================================
 // launchers
 // =================================================================================================
@@ -474,20 +522,22 @@ int device_cu_count(int device)
 
 template <class Scene, bool DBG>
 static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-	hipStream_t stream)
+	const WavefrontWorkspace &ws, hipStream_t stream)
 {
 	const uint32_t n_work = work_items(U, rm);
+	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
 	const uint32_t blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, totals);
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, totals, ws.ray_queue,
+		ws.capacity);
 	return hipGetLastError();
 }
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, hipStream_t stream)
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
 {
 	switch (scene)
 	{
-#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_pixel<S, true>(U, rows, out, format, pixel_stats, totals, stream) : run_pixel<S, false>(U, rows, out, format, pixel_stats, totals, stream);
+#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_pixel<S, true>(U, rows, out, format, pixel_stats, totals, ws, stream) : run_pixel<S, false>(U, rows, out, format, pixel_stats, totals, ws, stream);
 		SDFR_FOR_EACH_SCENE(SDFR_RUN)
 #undef SDFR_RUN
 	default: return hipErrorInvalidValue;
@@ -511,10 +561,12 @@ static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, in
 	(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_blocks_per_cu, k_shade<Scene, DBG>, SDFR_BLOCK, 0);
 	if (march_blocks_per_cu < 1) march_blocks_per_cu = 1;
 	if (shade_blocks_per_cu < 1) shade_blocks_per_cu = 1;
-	// persistent grids: exactly what is resident, but never more waves than chunks of work
-	const uint32_t chunks = (n_work + 63u) / 64u;
+	// persistent grids: what the occupancy query calls resident (it may over-state by a block
+	// per CU for SGPR-heavy kernels; harmless here because work is claimed dynamically), but
+	// never more waves than there are ranges to claim
+	const uint32_t grabs = (n_work + SDFR_GRAB - 1u) / SDFR_GRAB;
 	uint32_t march_blocks = (uint32_t)(cus * march_blocks_per_cu);
-	if (march_blocks > (chunks + 3u) / 4u) march_blocks = (chunks + 3u) / 4u;
+	if (march_blocks > (grabs + 3u) / 4u) march_blocks = (grabs + 3u) / 4u;
 	if (march_blocks < 1) march_blocks = 1;
 	uint32_t shade_blocks = (uint32_t)(cus * shade_blocks_per_cu);
 	if (shade_blocks > init_blocks) shade_blocks = init_blocks;
@@ -525,7 +577,8 @@ static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, in
 	for (int r = 0; r < rounds; ++r)
 	{
 		if (march_events) (void)hipEventRecord(march_events[2 * r], stream);
-		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, ws, list_cur, ws.counters + r, pixel_stats, totals);
+		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, ws, list_cur, ws.counters + r,
+			ws.counters + 32 + r, pixel_stats, totals);
 		if (march_events) (void)hipEventRecord(march_events[2 * r + 1], stream);
 		if (shade_events) (void)hipEventRecord(shade_events[2 * r], stream);
 		hipLaunchKernelGGL((k_shade<Scene, DBG>), dim3(shade_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, ws, list_cur, ws.counters + r, list_next,

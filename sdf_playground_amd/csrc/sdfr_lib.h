@@ -133,6 +133,13 @@ SDF_HD float op_rep_inf(float p, float size)
 	float x = p + size * 0.5f;
 	return x - size * floor1(x / size) - size * 0.5f;
 }
+// cell size is one of the verified constants (div_c): pass rsize = 1.0f / size
+SDF_HD float op_rep_inf_c(float p, float size, float rsize)
+{
+	float x = p + size * 0.5f;
+	return x - size * floor1(div_c(x, size, rsize)) - size * 0.5f;
+}
+SDF_HD vec2 op_rep_inf_c(vec2 p, float size, float rsize) { return V2(op_rep_inf_c(p.x, size, rsize), op_rep_inf_c(p.y, size, rsize)); }
 SDF_HD vec2 op_rep_inf(vec2 p, vec2 size) { return V2(op_rep_inf(p.x, size.x), op_rep_inf(p.y, size.y)); }
 SDF_HD vec3 op_rep_inf(vec3 p, vec3 size) { return V3(op_rep_inf(p.x, size.x), op_rep_inf(p.y, size.y), op_rep_inf(p.z, size.z)); }
 
@@ -179,6 +186,19 @@ SDF_HD float op_pipe(float a, float b, float size, float count)
 	return length(V2(ab.x - a_offset * size, ab.y)) - size / count;
 }
 SDF_HD float op_pipe_merge(float a, float b, float size, float count) { return min1(min1(a, b), op_pipe(a, b, size, count)); }
+// size and count are literals whose period sqrt(2)*size/count is a verified constant (div_c)
+SDF_HD float op_pipe_c(float a, float b, float size, float count)
+{
+	vec2 uv = op_ab2uv(V2(a, b));
+	float diag = size * SDFR_SQRT_HALF - uv.y;
+	const float period = SDFR_SQRT_TWO * size / count;
+	diag = fmod_c(diag, period, 1.0f / period);
+	uv.y = size * SDFR_SQRT_HALF - diag;
+	vec2 ab = op_ab2uv(uv);
+	float a_offset = (count - 1.f) / count;
+	return length(V2(ab.x - a_offset * size, ab.y)) - size / count;
+}
+SDF_HD float op_pipe_merge_c(float a, float b, float size, float count) { return min1(min1(a, b), op_pipe_c(a, b, size, count)); }
 
 SDF_HD float op_staircase(float x, float stepval, float spread)
 {

@@ -82,8 +82,48 @@ SDF_HD float abs1(float a) { return __builtin_fabsf(a); }
 SDF_HD float floor1(float a) { return __builtin_floorf(a); }
 SDF_HD float trunc1(float a) { return __builtin_truncf(a); }
 SDF_HD float rne1(float a) { return __builtin_rintf(a); }      // HLSL round(): half to even
-SDF_HD float sqrt1(float a) { return __builtin_sqrtf(a); }
-SDF_HD float rsqrt1(float a) { return 1.0f / __builtin_sqrtf(a); }
+// IEEE-754 correctly rounded square root.
+// Device: hipcc's generic lowering costs ~18 VALU instructions (input scaling, v_sqrt_f32,
+// integer next-up/next-down probes, class fix-ups) and sqrt is ~40 % of a scene evaluation,
+// so the kernels use Markstein's sequence on the hardware reciprocal-sqrt seed instead:
+//     y = rsq(a); g = a*y; h = y/2; g' = g + (a - g*g)*h      (both corrections fused)
+// The correctly rounded result is unique, so this is not an approximation: for a = +0 and
+// every a in [2^-96, FLT_MAX] the result is bit-identical to sqrtf -- checked exhaustively
+// over all 2^32 inputs on gfx950 (sdfr_selftest_math, tests/test_gpu_math.py; the sequence
+// is in fact exact down to 2^-102).  Outside that set (negative, -0, denormal/tiny, +inf)
+// it is NOT valid; every call site passes a sum of squares or a guarded discriminant of
+// scene-scale quantities, and the oracle's census build counts out-of-domain arguments over
+// the test and bench workloads (zero).  NaN propagates.
+SDF_HD float sqrt1(float a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(a, 0x1p-96f));
+	const float g = a * y;
+	const float h = 0.5f * y;
+	return __builtin_fmaf(__builtin_fmaf(-g, g, a), h, g);
+#else
+	return __builtin_sqrtf(a);
+#endif
+}
+// the generic lowering, valid for every input (reference for the self-test)
+SDF_HD float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
+SDF_HD float rsqrt1(float a) { return 1.0f / sqrt1(a); }
+
+// a / c for a constant c, rc = 1.0f / c folded at compile time:
+//     q = a*rc; q' = q + (a - c*q)*rc                        (both corrections fused)
+// instead of the ~11-instruction IEEE divide.  Bit-identical to a / c whenever no
+// intermediate under- or overflows: exhaustively checked for the constants the scenes use
+// (sdfr_selftest_math) over a = 0 and 2^-100 <= |a| <= 2^100.  Only for verified constants.
+SDF_HD float div_c(float a, float c, float rc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const float q = a * rc;
+	return __builtin_fmaf(__builtin_fmaf(-c, q, a), rc, q);
+#else
+	(void)rc;
+	return a / c;
+#endif
+}
 SDF_HD float sat1(float a) { return min1(max1(a, 0.f), 1.f); }
 SDF_HD float clamp1(float a, float lo, float hi) { return min1(max1(a, lo), hi); }
 SDF_HD float step1(float edge, float x) { return x >= edge ? 1.f : 0.f; }
@@ -94,6 +134,13 @@ SDF_HD float lerp1(float a, float b, float t) { return fma1(t, b - a, a); }
 SDF_HD float fmod1(float a, float b)
 {
 	float q = a / b;
+	float f = frac1(abs1(q));
+	return (q >= -q ? f : -f) * b;
+}
+// fmod1 for a verified constant divisor
+SDF_HD float fmod_c(float a, float b, float rb)
+{
+	float q = div_c(a, b, rb);
 	float f = frac1(abs1(q));
 	return (q >= -q ? f : -f) * b;
 }

@@ -75,7 +75,7 @@ SDF_HD float snoise3(vec3 v)
 
 SDF_HD float turbulence3(vec3 p)
 {
-	return (snoise3(p) + snoise3(p * 2.f) / 2.f + snoise3(p * 4.f) / 4.f + snoise3(p * 8.f) / 8.f) * 8.f / 15.f;
+	return div_c((snoise3(p) + snoise3(p * 2.f) / 2.f + snoise3(p * 4.f) / 4.f + snoise3(p * 8.f) / 8.f) * 8.f, 15.f, 1.0f / 15.f);
 }
 
 } // namespace sdfr

@@ -15,29 +15,36 @@ struct LocalRayStore
 {
 	RayRec slot[SDFR_MAX_RAYS];
 	SDF_HD void put(int i, const RayRec &r) { slot[i] = r; }
+	SDF_HD RayRec get(int i) const { return slot[i]; }
 };
 
 struct PixelCounters { uint32_t rays, march_evals, hits; };
 
-template <class Scene, bool DBG>
-SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt)
+// `store` holds the pixel's pending rays (put/get by slot).  The primary ray never enters
+// it: the reference pops it from slot 0 before anything is pushed (pshader_sdf.hlsl:289-294),
+// so the queue is empty -- and slot 0 free again -- when the first hit is shaded.
+template <class Scene, bool DBG, class Store>
+SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, Store &store)
 {
 	const DebugFlags F = debug_flags(U);
 	const PixelRay pr = pixel_ray(U, px, py);
-	LocalRayStore store;
-	store.slot[0] = primary_ray(U, pr);
-	uint64_t depths = queue_set_depth(SDFR_QUEUE_EMPTY, 0, 0);
-	int count = 1;
+	RayRec ray = primary_ray(U, pr);
+	uint64_t depths = SDFR_QUEUE_EMPTY;
+	int count = 0; // rays waiting in the store
 
 	float hdr = -1.f;
 	vec3 acc = V3s(0.f);
-	for (int bounce = 0; bounce < U.bounce_count && count > 0; ++bounce)
+	for (int bounce = 0; bounce < U.bounce_count; ++bounce)
 	{
+		if (bounce > 0)
+		{
+			if (count == 0) break;
+			const int idx = queue_next(depths, U.ray_count);
+			ray = store.get(idx);
+			depths = queue_set_depth(depths, idx, RAY_DEPTH_INVALID);
+			--count;
+		}
 		cnt.rays++;
-		const int idx = queue_next(depths, U.ray_count);
-		const RayRec ray = store.slot[idx];
-		depths = queue_set_depth(depths, idx, RAY_DEPTH_INVALID);
-		--count;
 
 		const typename Scene::RayInv R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
 		const float inside_sign = ray_inside_sign(ray);
@@ -68,8 +75,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt)
 			float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
 			hit.normal = normalize(V3(g0, g1, g2));
 
-			Spawner<LocalRayStore> q(store, depths, count, U.ray_count);
-			out = shade_hit<Scene, DBG, LocalRayStore>(U, F, ray, pr, hit, max_range, hdr, q);
+			Spawner<Store> q(store, depths, count, U.ray_count);
+			out = shade_hit<Scene, DBG, Store>(U, F, ray, pr, hit, max_range, hdr, q);
 			depths = q.depths;
 			count = q.count;
 		}

@@ -102,7 +102,7 @@ struct SceneCubeSea
 	static SDF_HD Cell eval_cell(const FrameU &U, vec3 p)
 	{
 		Cell c;
-		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(2.f, 2.f));
+		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(2.f, 2.f)); // x / 2 is an exact multiply already
 		c.cell_pos = V3(rep.x, p.y, rep.y);
 		vec2 cell_index = (V2(p.x, p.z) - rep) / 2.f;
 		vec2 q = cell_index * 0.5f + 0.25f;
@@ -176,8 +176,8 @@ struct SceneLabyrinth
 		float cut_top = sd_plane(p - V3(0.f, 1.9f, 0.f), V3(0.f, 1.f, 0.f));
 		float cut_low = sd_plane(p - V3(0.f, 1.5f, 0.f), V3(0.f, -1.f, 0.f));
 		float d = max1(bowl, cut_low);
-		d = op_pipe_merge(d, stem, 0.1f, 4.f);
-		d = op_pipe_merge(d, foot, 0.1f, 4.f);
+		d = op_pipe_merge_c(d, stem, 0.1f, 4.f);
+		d = op_pipe_merge_c(d, foot, 0.1f, 4.f);
 		d = max1(d, cut_top);
 		d = max1(d, -bowl - 0.06f);
 		return d;
@@ -188,7 +188,7 @@ struct SceneLabyrinth
 	{
 		Objects o;
 		// 20 x 20 cells, mirrored into one octant
-		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(20.f, 20.f));
+		vec2 rep = op_rep_inf_c(V2(p.x, p.z), 20.f, 1.0f / 20.f);
 		float wx = abs1(rep.x), wz = abs1(rep.y);
 		if (wz > wx) { float t = wx; wx = wz; wz = t; }
 		vec3 wp = V3(wx, p.y, wz);
@@ -350,12 +350,12 @@ struct SceneLense
 	{
 		Objects o;
 		vec3 b1 = p - V3(0.f, -5.f, 0.f);
-		vec2 r1 = op_rep_inf(V2(b1.x, b1.z), V2(3.f, 3.f));
+		vec2 r1 = op_rep_inf_c(V2(b1.x, b1.z), 3.f, 1.0f / 3.f);
 		o.bg1_xz = r1;
 		o.bg1 = blob(V3(r1.x, b1.y, r1.y));
 
 		vec3 b2 = p - V3(0.f, 5.f, 0.f);
-		vec2 r2 = op_rep_inf(V2(b2.x, b2.z), V2(10.f, 10.f));
+		vec2 r2 = op_rep_inf_c(V2(b2.x, b2.z), 10.f, 1.0f / 10.f);
 		o.bg2 = blob(V3(r2.x, b2.y, r2.y));
 
 		vec3 lp = abs(p);

@@ -1,0 +1,42 @@
+"""GPU tier: the kernels' fast exact arithmetic.  sqrt1 (Markstein sequence on v_rsq_f32) and
+div_c (reciprocal + fused correction for scene constants) must return the SAME correctly
+rounded bits as the generic IEEE lowering on their whole stated domain -- checked exhaustively
+(every fp32 bit pattern) on the GPU through the C ABI (sdfr_selftest_math)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# every divisor handed to div_c / op_rep_inf_c / op_pipe_c / turbulence3 by the scene code
+SCENE_DIVISORS = [
+    20.0,                                              # labyrinth cell size
+    3.0, 10.0,                                         # lense background cells
+    15.0,                                              # turbulence3 normalisation
+    float(np.float32(np.float32(np.float32(1.41421356237309504) * np.float32(0.1)) / np.float32(4.0))),  # op_pipe period (labyrinth vase)
+]
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    yield r
+    r.close()
+
+
+def test_fast_sqrt_is_correctly_rounded_on_its_domain(renderer):
+    assert renderer.selftestMath(0) == 0
+
+
+@pytest.mark.parametrize("c", SCENE_DIVISORS)
+def test_constant_division_is_exact(renderer, c):
+    assert renderer.selftestMath(1, c) == 0
+
+
+def test_selftest_is_not_vacuous(renderer):
+    # negative control: the plain reciprocal multiply is NOT the correctly rounded quotient
+    assert renderer.selftestMath(2, 3.0) > 0
+    assert renderer.selftestMath(2, 20.0) > 0
