@@ -21,10 +21,28 @@
 namespace orc {
 
 #ifdef ORACLE_CENSUS
-struct Census { unsigned long long flops; unsigned long long transc; };
-inline Census &census() { static thread_local Census c = {0, 0}; return c; }
+struct Census
+{
+	unsigned long long flops, transc;
+	// arguments outside the domain on which the GPU kernels' fast exact sequences are valid
+	// (sdf_playground_amd/csrc/sdfr_math.h: sqrt1, div_c); must stay 0 on every workload
+	unsigned long long sqrt_out_of_domain, divc_out_of_domain;
+};
+inline Census &census() { static thread_local Census c = {0, 0, 0, 0}; return c; }
+inline void census_check_sqrt(float a)
+{
+	uint32_t u = dm::f2u(a);
+	if (!(u == 0u || (a >= 0x1p-96f && a <= 3.402823466e+38f))) census().sqrt_out_of_domain++;
+}
+inline void census_check_divc(float a)
+{
+	float m = fabsf(a);
+	if (!(dm::f2u(a) == 0u || (m >= 0x1p-100f && m <= 0x1p100f))) census().divc_out_of_domain++;
+}
 #define ORC_COUNT(n) (census().flops += (n))
 #define ORC_COUNT_T() (census().flops += 1, census().transc += 1)
+#define ORC_CHECK_SQRT(a) census_check_sqrt(a)
+#define ORC_CHECK_DIVC(a) census_check_divc(a)
 struct real
 {
 	float v;
@@ -54,6 +72,8 @@ typedef float real;
 inline float val(real a) { return a; }
 #define ORC_COUNT(n) ((void)0)
 #define ORC_COUNT_T() ((void)0)
+#define ORC_CHECK_SQRT(a) ((void)0)
+#define ORC_CHECK_DIVC(a) ((void)0)
 #endif
 
 typedef unsigned int uint;
@@ -65,8 +85,11 @@ inline real r_floor(real a) { ORC_COUNT(1); return real(floorf(val(a))); }
 inline real r_trunc(real a) { ORC_COUNT(1); return real(truncf(val(a))); }
 // HLSL round() is round-half-to-even (a-T.1)
 inline real r_round(real a) { ORC_COUNT(1); return real(rintf(val(a))); }
-inline real r_sqrt(real a) { ORC_COUNT(1); return real(sqrtf(val(a))); }
-inline real r_rsqrt(real a) { ORC_COUNT(1); return real(1.0f / sqrtf(val(a))); }
+inline real r_sqrt(real a) { ORC_COUNT(1); ORC_CHECK_SQRT(val(a)); return real(sqrtf(val(a))); }
+inline real r_rsqrt(real a) { ORC_COUNT(1); ORC_CHECK_SQRT(val(a)); return real(1.0f / sqrtf(val(a))); }
+// a / c where c is a scene constant: plain IEEE division here; the census build records
+// numerators outside the range on which the kernels' div_c is verified
+inline real r_div_const(real a, real c) { ORC_CHECK_DIVC(val(a)); return a / c; }
 inline real r_sin(real a) { ORC_COUNT_T(); return real(dm::sinf_det(val(a))); }
 inline real r_cos(real a) { ORC_COUNT_T(); return real(dm::cosf_det(val(a))); }
 inline real r_atan2(real y, real x) { ORC_COUNT_T(); return real(dm::atan2f_det(val(y), val(x))); }
@@ -106,6 +129,14 @@ inline real r_lerp(real a, real b, real t) { return r_fma(t, b - a, a); }
 inline real r_fmod(real a, real b)
 {
 	real r = a / b;
+	real f = r_frac(r_abs(r));
+	real s = (r >= -r) ? f : -f;
+	return s * b;
+}
+// the same with a scene-constant divisor (see r_div_const)
+inline real r_fmod_const(real a, real b)
+{
+	real r = r_div_const(a, b);
 	real f = r_frac(r_abs(r));
 	real s = (r >= -r) ? f : -f;
 	return s * b;

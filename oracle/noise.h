@@ -103,7 +103,7 @@ inline real snoise(float3 v)
 // noise.hlsl:473-476
 inline real turbulence(float3 pos)
 {
-	return (snoise(pos) + snoise(pos * real(2.f)) / real(2.f) + snoise(pos * real(4.f)) / real(4.f) + snoise(pos * real(8.f)) / real(8.f)) * real(8.f) / real(15.f);
+	return r_div_const((snoise(pos) + snoise(pos * real(2.f)) / real(2.f) + snoise(pos * real(4.f)) / real(4.f) + snoise(pos * real(8.f)) / real(8.f)) * real(8.f), real(15.f));
 }
 
 } // namespace orc

@@ -293,8 +293,15 @@ int orc_render(const char *scene, const orc_frame *frame, float *out_rgba, unsig
 
 #ifdef ORACLE_CENSUS
 // flop census of the calling thread (render with nthreads = 1): {flops, transcendentals}
-void orc_census_reset() { census().flops = 0; census().transc = 0; }
-void orc_census_get(unsigned long long *out2) { out2[0] = census().flops; out2[1] = census().transc; }
+void orc_census_reset() { census() = Census{0, 0, 0, 0}; }
+// {flops, transcendentals, sqrt arguments out of domain, constant-division numerators out of domain}
+void orc_census_get(unsigned long long *out4)
+{
+	out4[0] = census().flops;
+	out4[1] = census().transc;
+	out4[2] = census().sqrt_out_of_domain;
+	out4[3] = census().divc_out_of_domain;
+}
 #endif
 
 // Known-answer access to individual library functions (tests/test_oracle_*.py).

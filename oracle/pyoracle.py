@@ -226,12 +226,18 @@ def tonemap_png(rgba, path):
 
 def census(scene, frame, step=(1, 1), region=None):
     """Operation census of the oracle (liboracle_census.so, -DORACLE_CENSUS): renders the
-    sample single-threaded and returns (rgba, totals[4], flops, transcendentals).
+    sample single-threaded and returns (rgba, totals[4], flops, transcendentals);
+    census.last_domain_violations = (sqrt arguments, constant-division numerators) that fall
+    outside the domain of the kernels' fast exact sequences (must be (0, 0)).
     Counting rule: + - * / sqrt rsqrt min max compare select floor/round = 1,
     fma = 2, each transcendental (sin cos atan2 exp2 log2) = 1, abs/neg = 0."""
     L = lib(census=True)
     L.orc_census_reset()
     out, _, totals = render(scene, frame, region=region, step=step, nthreads=1, census=True)
-    c = np.zeros(2, np.uint64)
+    c = np.zeros(4, np.uint64)
     L.orc_census_get(c.ctypes.data_as(ctypes.c_void_p))
+    census.last_domain_violations = (int(c[2]), int(c[3]))
     return out, totals, int(c[0]), int(c[1])
+
+
+census.last_domain_violations = (0, 0)

@@ -284,7 +284,7 @@ inline float3 opRepInf(float3 pos, float3 size)
 inline float2 opRepInf(float2 pos, float2 size)
 {
 	float2 x = pos + size * real(0.5f);
-	return x - size * v_floor(x / size) - size * real(0.5f);
+	return x - size * v_floor(float2(r_div_const(x.x, size.x), r_div_const(x.y, size.y))) - size * real(0.5f);
 }
 inline real opRepInf(real pos, real size)
 {
@@ -332,7 +332,7 @@ inline real opPipe(real a, real b, real size, real count)
 	float2 ab = float2(a, b);
 	float2 uv = opAB2UV(ab);
 	real diag = size * real(sqrt_half) - uv.y;
-	diag = r_fmod(diag, real(sqrt_two) * size / count);
+	diag = r_fmod_const(diag, real(sqrt_two) * size / count);
 	uv.y = size * real(sqrt_half) - diag;
 	ab = opAB2UV(uv);
 

@@ -1,0 +1,75 @@
+"""CPU tier, world_size = 2, gloo: the multi-rank path of bench.py -- 8-row strips dealt
+round-robin over ranks, one gather to rank 0, scatter into the image.  On the
+CPU the strips are rendered by the oracle (there is no GPU here); the partition, the gather
+and the assembly are the code the GPU path uses (sdf_playground_amd strip helpers)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+W, H = 40, 27  # ragged last strip
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import sdf_playground_amd as sp
+    from oracle import pyoracle as po
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = po.default_frame("labyrinth", W, H, stime=0.5)
+    n = sp.strip_buffer_pixels_host(W, H, world)
+    local = np.zeros((n // W, W, 4), np.float32)
+    rows = sp.strip_rows_of_rank(H, rank, world)
+    full = np.zeros((H, W, 4), np.float32)
+    for row in rows:  # this rank renders only its own rows
+        po.render("labyrinth", f, region=(0, row, W, row + 1), out=full, nthreads=1)
+    for row in rows:
+        strip = row // sp.STRIP_ROWS
+        local[(strip // world) * sp.STRIP_ROWS + row % sp.STRIP_ROWS] = full[row]
+    t = torch.from_numpy(local.reshape(n, 4))
+    if rank == 0:
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.gather(t, gather_list=gathered, dst=0)
+        img = sp.assemble_strips_host(W, H, world, torch.stack(gathered).numpy())
+        np.save(out_path, img)
+    else:
+        dist.gather(t, dst=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_strip_gather_matches_single_rank(oracle, tmp_path, world):
+    out_path = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    img = np.load(out_path)
+    f = oracle.default_frame("labyrinth", W, H, stime=0.5)
+    ref, _, _ = oracle.render("labyrinth", f)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_strip_partition_covers_every_row_once():
+    import sdf_playground_amd as sp
+
+    for h in (1, 7, 8, 9, 27, 64, 2160):
+        for world in (1, 2, 3, 4, 8):
+            rows = sorted(r for k in range(world) for r in sp.strip_rows_of_rank(h, k, world))
+            assert rows == list(range(h))
+            assert all(len(sp.strip_rows_of_rank(h, k, world)) * 1 <= sp.strip_buffer_pixels_host(1, h, world) for k in range(world))

@@ -208,3 +208,26 @@ def test_error_behaviour(oracle):
         v = r.getVariableMap()[row[0]]
         assert (v.minval, v.maxval, v.start, v.step, v.value) == tuple(np.float32(x) for x in row[1:6])
     r.close()
+
+
+def test_kernels_reproduce_golden_fixtures(renderer):
+    """Committed fixtures (tests/golden, tools/make_golden.py): no oracle in the loop."""
+    import golden_util as gu
+    import sdf_playground_amd as sp
+
+    for path in gu.golden_files():
+        g = np.load(path)
+        scene = gu.scene_of(path)
+        renderer.initShader(scene)
+        renderer.setParameters(float(g["stime"]))
+        renderer.setLimits(iter_count=int(g["iter_count"]), bounce_count=int(g["bounce_count"]), ray_count=int(g["ray_count"]),
+                           light_count=int(g["light_count"]), range=float(g["range"]), max_cost_default=int(g["max_cost_default"]))
+        b = g["basis"]
+        renderer.setCameraBasis(b[0], b[1], b[2], b[3])
+        w, h = int(g["width"]), int(g["height"])
+        for schedule in (0, 1):
+            renderer.setSchedule(schedule)
+            img, st = renderer.render(None, w, h, pixel_stats=True)
+            assert np.abs(img.astype(np.float64) - g["rgba"]).max() <= TOL
+            assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32)), path
+            assert np.array_equal(st, g["stats"].astype(np.uint32)), path
