@@ -17,6 +17,8 @@
 // min max compare select = 1, fma = 2, abs/neg = 0) for the roofline numerator.
 #pragma once
 #include "detmath.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace orc {
 
@@ -26,7 +28,7 @@ struct Census
 	unsigned long long flops, transc;
 	// arguments outside the domain on which the GPU kernels' fast exact sequences are valid
 	// (sdf_playground_amd/csrc/sdfr_math.h: sqrt1, div_c); must stay 0 on every workload
-	unsigned long long sqrt_out_of_domain, divc_out_of_domain;
+	unsigned long long sqrt_out_of_domain, divc_out_of_domain; // (the latter also counts fast-plane heights)
 };
 inline Census &census() { static thread_local Census c = {0, 0, 0, 0}; return c; }
 inline void census_check_sqrt(float a)
@@ -37,12 +39,22 @@ inline void census_check_sqrt(float a)
 inline void census_check_divc(float a)
 {
 	float m = fabsf(a);
-	if (!(dm::f2u(a) == 0u || (m >= 0x1p-100f && m <= 0x1p100f))) census().divc_out_of_domain++;
+	if (!(m == 0.f || (m >= 0x1p-100f && m <= 0x1p100f))) census().divc_out_of_domain++;
+}
+inline void census_check_plane(float a, float c)
+{
+	float m = fabsf(a);
+	if (!(m == 0.f || (m >= 0x1p-60f && m <= 0x1p40f)) || !(c >= 1e-20f && c <= 2.f))
+	{
+		census().divc_out_of_domain++;
+		if (getenv("ORC_CENSUS_VERBOSE")) fprintf(stderr, "plane out of domain: height %a (%g) denom %a\n", a, a, c);
+	}
 }
 #define ORC_COUNT(n) (census().flops += (n))
 #define ORC_COUNT_T() (census().flops += 1, census().transc += 1)
 #define ORC_CHECK_SQRT(a) census_check_sqrt(a)
 #define ORC_CHECK_DIVC(a) census_check_divc(a)
+#define ORC_CHECK_PLANE(a, c) census_check_plane(a, c)
 struct real
 {
 	float v;
@@ -74,6 +86,7 @@ inline float val(real a) { return a; }
 #define ORC_COUNT_T() ((void)0)
 #define ORC_CHECK_SQRT(a) ((void)0)
 #define ORC_CHECK_DIVC(a) ((void)0)
+#define ORC_CHECK_PLANE(a, c) ((void)0)
 #endif
 
 typedef unsigned int uint;

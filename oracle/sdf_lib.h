@@ -187,7 +187,11 @@ inline real sdPlaneFast(float3 pos, float4 dir, float3 plane_norm)
 {
 	real plane_dist = dot(pos, plane_norm);
 	if (any(dir.w))
-		return plane_dist / (r_saturate(dot(dir.xyz(), -plane_norm)) + real(1e-20f));
+	{
+		real denom = r_saturate(dot(dir.xyz(), -plane_norm)) + real(1e-20f);
+		ORC_CHECK_PLANE(val(plane_dist), val(denom));
+		return plane_dist / denom;
+	}
 	else
 		return plane_dist;
 }

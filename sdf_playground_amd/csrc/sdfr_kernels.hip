@@ -477,6 +477,8 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, 
 // what = 0: sqrt1(a) against the generic IEEE lowering for a = +0 and every a in [2^-96, FLT_MAX]
 // what = 1: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-100 <= |a| <= 2^100
 // what = 2: negative control -- the plain reciprocal multiply a * (1/c) on the same inputs (must differ)
+// what = 3: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-60 <= |a| <= 2^40 (the fast
+//           ground plane: numerator = height above the floor, c = per-ray denominator in [1e-20, 2])
 __global__ __launch_bounds__(SDFR_BLOCK) void k_selftest_math(int what, float c, unsigned long long *mismatches)
 {
 	const unsigned long long stride = (unsigned long long)gridDim.x * SDFR_BLOCK;
@@ -495,9 +497,14 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_selftest_math(int what, float c,
 		else
 		{
 			const float m = abs1(a);
-			if (!(u == 0) && !(m >= 0x1p-100f && m <= 0x1p100f)) continue;
+			if (what == 3)
+			{
+				if (!(m == 0.f) && !(m >= 0x1p-60f && m <= 0x1p40f)) continue;
+			}
+			else if (!(m == 0.f) && !(m >= 0x1p-100f && m <= 0x1p100f))
+				continue;
 			ref = a / c;
-			got = what == 1 ? div_c(a, c, rc) : a * rc;
+			got = what == 2 ? a * rc : div_c(a, c, rc);
 		}
 		if (__float_as_uint(ref) != __float_as_uint(got)) bad++;
 	}

@@ -86,7 +86,8 @@ SDF_HD float rne1(float a) { return __builtin_rintf(a); }      // HLSL round(): 
 // Device: hipcc's generic lowering costs ~18 VALU instructions (input scaling, v_sqrt_f32,
 // integer next-up/next-down probes, class fix-ups) and sqrt is ~40 % of a scene evaluation,
 // so the kernels use Markstein's sequence on the hardware reciprocal-sqrt seed instead:
-//     y = rsq(a); g = a*y; h = y/2; g' = g + (a - g*g)*h      (both corrections fused)
+//     y = rsq(a + 2^-126); g = a*y; h = y/2; g' = g + (a - g*g)*h   (both corrections fused)
+// (the 2^-126 bias keeps rsq finite at a = 0 and is below half an ulp of every a >= 2^-96)
 // The correctly rounded result is unique, so this is not an approximation: for a = +0 and
 // every a in [2^-96, FLT_MAX] the result is bit-identical to sqrtf -- checked exhaustively
 // over all 2^32 inputs on gfx950 (sdfr_selftest_math, tests/test_gpu_math.py; the sequence
@@ -97,7 +98,7 @@ SDF_HD float rne1(float a) { return __builtin_rintf(a); }      // HLSL round(): 
 SDF_HD float sqrt1(float a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(a, 0x1p-96f));
+	const float y = __builtin_amdgcn_rsqf(a + 0x1p-126f);
 	const float g = a * y;
 	const float h = 0.5f * y;
 	return __builtin_fmaf(__builtin_fmaf(-g, g, a), h, g);
@@ -110,15 +111,16 @@ SDF_HD float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
 SDF_HD float rsqrt1(float a) { return 1.0f / sqrt1(a); }
 
 // a / c for a constant c, rc = 1.0f / c folded at compile time:
-//     q = a*rc; q' = q + (a - c*q)*rc                        (both corrections fused)
+//     q = a*rc; t = fma(c, q, -a); q' = fma(-t, rc, q)       (= q + (a - c*q)*rc; written so
+//     that a = -0 gives -0: the residual of a zero numerator must be -0, not +0)
 // instead of the ~11-instruction IEEE divide.  Bit-identical to a / c whenever no
 // intermediate under- or overflows: exhaustively checked for the constants the scenes use
-// (sdfr_selftest_math) over a = 0 and 2^-100 <= |a| <= 2^100.  Only for verified constants.
+// (sdfr_selftest_math) over a = +-0 and 2^-100 <= |a| <= 2^100.  Only for verified constants.
 SDF_HD float div_c(float a, float c, float rc)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	const float q = a * rc;
-	return __builtin_fmaf(__builtin_fmaf(-c, q, a), rc, q);
+	return __builtin_fmaf(-__builtin_fmaf(c, q, -a), rc, q);
 #else
 	(void)rc;
 	return a / c;

@@ -22,11 +22,22 @@ namespace sdfr {
 
 // Ray-dependent part of the shared checker floor (sdf_common.hlsl:62-83 via
 // sdf_primitives.hlsl:59-70): the fast plane divides by saturate(dot(dir, -n)) + 1e-20.
-SDF_HD float ground_denominator(vec3 dir) { return sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f; }
-SDF_HD float ground_dist(vec3 p, bool fast, float denom)
+// The division height / denominator is made once per ray into a reciprocal and then done per
+// step with div_c (sdfr_math.h): bit-identical to the IEEE divide for height = 0 and
+// 2^-60 <= |height| <= 2^40 with any denominator in [1e-20, 2] (sdfr_selftest_math what = 3,
+// swept over random and adversarial denominators in tests/test_gpu_math.py).
+struct GroundInv { float denom, rdenom; };
+SDF_HD GroundInv ground_setup(vec3 dir)
+{
+	GroundInv g;
+	g.denom = sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f;
+	g.rdenom = 1.0f / g.denom;
+	return g;
+}
+SDF_HD float ground_dist(vec3 p, bool fast, const GroundInv &g)
 {
 	float d = dot(p, V3(0.f, 1.f, 0.f));
-	return fast ? d / denom : d;
+	return fast ? div_c(d, g.denom, g.rdenom) : d;
 }
 SDF_HD void ground_material(const SurfacePoint &sp, Material &m)
 {
@@ -58,16 +69,16 @@ struct SceneFastSphere
 	static const char *name() { return "fast_sphere"; }
 	static const char *variables() { return ""; }
 	static void prepare(FrameU &) {}
-	struct RayInv { float ground_denom; };
+	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		return r;
 	}
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		return min1(d, sd_sphere_fast(p - V3(0.f, 1.f, 0.f), dir, fast, 0.5f));
 	}
 	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
@@ -89,11 +100,11 @@ struct SceneCubeSea
 	static const char *name() { return "cube_sea"; }
 	static const char *variables() { return ""; }
 	static void prepare(FrameU &) {}
-	struct RayInv { float ground_denom; vec2 barrier; };
+	struct RayInv { GroundInv ground; vec2 barrier; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		// cell-wall guard (sdf_primitives.hlsl:118-124): which wall the ray runs towards
 		r.barrier = (V2(step1(0.f, dir.x), step1(0.f, dir.z)) - 0.5f) * V2(2.01f, 2.01f);
 		return r;
@@ -118,7 +129,7 @@ struct SceneCubeSea
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		Cell c = eval_cell(U, p);
 		d = min1(d, c.cube);
 		vec2 t = (R.barrier - V2(c.cell_pos.x, c.cell_pos.z)) / V2(dir.x, dir.z);
@@ -157,11 +168,11 @@ struct SceneLabyrinth
 
 	static SDF_HD float fire_cone(vec3 p) { return sd_round_cone(p, V3(0.f, 1.1f, 0.f), V3(0.f, 1.6f, 0.f), 0.15f, 0.1f); }
 
-	struct RayInv { float ground_denom; bool skip_fire; };
+	struct RayInv { GroundInv ground; bool skip_fire; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		// a ray continuing through a transparent surface ignores the fire it just left
 		// (OBJECT_TRANSPARENT, pshader_sdf.hlsl:80; sdf_scene_labyrinth.hlsl:55,62)
 		r.skip_fire = f.has_transparent && fire_cone(f.last_transparent_pos) < SDFR_DIST_EPS;
@@ -214,7 +225,7 @@ struct SceneLabyrinth
 	}
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		Objects o = eval_objects(p);
 		d = min1(d, o.wall);
 		d = min1(d, o.vase);
@@ -256,11 +267,11 @@ struct SceneFractal
 	static const char *name() { return "fractal"; }
 	static const char *variables() { return ""; }
 	static void prepare(FrameU &) {}
-	struct RayInv { float ground_denom; };
+	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		return r;
 	}
 	// order (a, b, c) so that a >= b >= c, as three compare-exchanges
@@ -299,7 +310,7 @@ struct SceneFractal
 	}
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		float lvl;
 		return min1(d, fold(p, &lvl));
 	}
@@ -444,11 +455,11 @@ struct SceneGems
 		U.su[SU_ROT_S] = sc.x;
 		U.su[SU_ROT_C] = sc.y;
 	}
-	struct RayInv { float ground_denom; };
+	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		return r;
 	}
 	static SDF_HD float gems(const FrameU &U, vec3 p, float *ring_index)
@@ -466,7 +477,7 @@ struct SceneGems
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		float idx;
 		return min1(d, gems(U, p, &idx));
 	}
@@ -520,11 +531,11 @@ struct SceneLightShadows
 			U.su[SU_COLORS + 3 * i + 2] = c.z;
 		}
 	}
-	struct RayInv { float ground_denom; bool is_shadow; };
+	struct RayInv { GroundInv ground; bool is_shadow; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
-		r.ground_denom = ground_denominator(dir);
+		r.ground = ground_setup(dir);
 		r.is_shadow = f.is_shadow;
 		return r;
 	}
@@ -539,7 +550,7 @@ struct SceneLightShadows
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground_denom));
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		if (!R.is_shadow) // the light bulbs do not shadow their own light
 		{
 #pragma unroll

@@ -36,6 +36,18 @@ def test_constant_division_is_exact(renderer, c):
     assert renderer.selftestMath(1, c) == 0
 
 
+def test_fast_ground_plane_division_is_exact(renderer):
+    """height / denominator with a per-ray reciprocal (sdfr_scenes.h: ground_dist): any
+    denominator the fast plane can produce, all heights in range."""
+    rng = np.random.default_rng(1)
+    cs = list(np.exp(rng.uniform(np.log(1e-20), np.log(2.0), 48)).astype(np.float32)) + [np.float32(1e-20), np.float32(1.0), np.float32(1.0) + np.float32(1e-20)]
+    for e in (-60, -20, -1, 0):  # adversarial significands
+        for m in (0x7FFFFF, 0x000001, 0x555555, 0x400001):
+            cs.append(np.uint32(((127 + e) << 23) | m).view(np.float32))
+    for c in cs:
+        assert renderer.selftestMath(3, float(c)) == 0, float(c)
+
+
 def test_selftest_is_not_vacuous(renderer):
     # negative control: the plain reciprocal multiply is NOT the correctly rounded quotient
     assert renderer.selftestMath(2, 3.0) > 0
