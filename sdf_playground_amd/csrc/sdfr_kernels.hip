@@ -180,8 +180,9 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint3
 	PixelCoord pc;
 	if (w < n_work && work_to_pixel(U, rm, w, pc))
 	{
-		GlobalRayStore store = {ray_queue, cap, pc.pid};
-		vec4 v = render_pixel<Scene, DBG, GlobalRayStore>(U, pc.px, pc.py, c, store);
+		GlobalRayStore backing = {ray_queue, cap, pc.pid};
+		CachedRayStore<GlobalRayStore> store(backing);
+		vec4 v = render_pixel<Scene, DBG, CachedRayStore<GlobalRayStore>>(U, pc.px, pc.py, c, store);
 		store_pixel(out, format, pc.pid, v);
 		if (pixel_stats)
 		{

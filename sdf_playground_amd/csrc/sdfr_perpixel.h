@@ -18,6 +18,34 @@ struct LocalRayStore
 	SDF_HD RayRec get(int i) const { return slot[i]; }
 };
 
+// Write-behind cache of depth one in front of a ray store: the most recently pushed ray stays
+// in registers and reaches the backing store only when another push follows.  Most pixels
+// spawn a single child (the shadow ray) that is popped right away, so its 44-byte record never
+// travels to HBM and back.
+template <class Backing>
+struct CachedRayStore
+{
+	Backing &backing;
+	RayRec cached;
+	int cached_slot;
+	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
+	SDF_HD void put(int i, const RayRec &r)
+	{
+		if (cached_slot >= 0) backing.put(cached_slot, cached);
+		cached = r;
+		cached_slot = i;
+	}
+	SDF_HD RayRec get(int i)
+	{
+		if (i == cached_slot)
+		{
+			cached_slot = -1;
+			return cached;
+		}
+		return backing.get(i);
+	}
+};
+
 struct PixelCounters { uint32_t rays, march_evals, hits; };
 
 // `store` holds the pixel's pending rays (put/get by slot).  The primary ray never enters

@@ -10,7 +10,8 @@
 
 using namespace sdfr;
 
-typedef vec4 (*pixel_fn)(const FrameU &, int, int, PixelCounters &, LocalRayStore &);
+typedef CachedRayStore<LocalRayStore> HostStore; // same store stack as the pixel kernel
+typedef vec4 (*pixel_fn)(const FrameU &, int, int, PixelCounters &, HostStore &);
 
 extern "C" int hostsim_render(const char *scene, FrameU *frame, float *out_rgba, unsigned *out_stats, int nthreads)
 {
@@ -20,7 +21,7 @@ extern "C" int hostsim_render(const char *scene, FrameU *frame, float *out_rgba,
 	pixel_fn fn = nullptr;
 	switch (si)
 	{
-#define SDFR_FN(I, S) case I: fn = frame_needs_debug(*frame) ? &render_pixel<S, true, LocalRayStore> : &render_pixel<S, false, LocalRayStore>; break;
+#define SDFR_FN(I, S) case I: fn = frame_needs_debug(*frame) ? &render_pixel<S, true, HostStore> : &render_pixel<S, false, HostStore>; break;
 		SDFR_FOR_EACH_SCENE(SDFR_FN)
 #undef SDFR_FN
 	}
@@ -34,7 +35,8 @@ extern "C" int hostsim_render(const char *scene, FrameU *frame, float *out_rgba,
 			for (int x = 0; x < U.width; ++x)
 			{
 				PixelCounters c = {0, 0, 0};
-				LocalRayStore store;
+				LocalRayStore backing;
+				HostStore store(backing);
 				vec4 v = fn(U, x, y, c, store);
 				size_t idx = (size_t)y * U.width + x;
 				out_rgba[4 * idx + 0] = v.x;
