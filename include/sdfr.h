@@ -122,6 +122,12 @@ int64_t sdfr_strip_buffer_pixels(int width, int height, int world);
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format);
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format);
 
+/* ---- the consumer of the render target: HDR::process
+ *      (Postprocessing.cpp:130-174; bloom.hlsl; pshader_hdr.hlsl).  scene = the RGBA16F frame of
+ *      sdfr_render; bloom_scratch = width*height*8 bytes; out = R8G8B8A8_UNORM (Graphics.cpp:65).
+ *      Device pointers; enqueued on the handle's stream. ------------------------------------------ */
+int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_rgba16f, void *bloom_scratch_rgba16f, void *out_rgba8);
+
 int sdfr_sync(sdfr_renderer *r);
 
 /* ---- observability: GPUProfiler::profile("setup"/"draw") (SDFRenderer.cpp:100,104) ---------- */

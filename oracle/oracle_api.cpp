@@ -14,6 +14,7 @@
 // line-by-line restatement, self-checked with analytic known-answer tests.
 #include "driver.h"
 #include "host.h"
+#include "postprocess.h"
 #include "scenes.h"
 
 #include <atomic>
@@ -303,6 +304,26 @@ void orc_census_get(unsigned long long *out4)
 	out4[3] = census().divc_out_of_domain;
 }
 #endif
+
+// HDR::process restated (oracle/postprocess.h).  scene: RGBA16F [h][w][4]; bloom1/bloom2:
+// RGBA16F scratch/outputs (may be inspected by tests); ldr: RGBA8 [h][w][4].
+void orc_postprocess(const unsigned short *scene, int w, int h, unsigned short *bloom1, unsigned short *bloom2, unsigned char *ldr)
+{
+	post::Image16 s = {w, h, scene};
+	post::bloom_horizontal(s, bloom1);
+	post::Image16 b1 = {w, h, bloom1};
+	post::bloom_vertical(b1, bloom2);
+	post::Image16 b2 = {w, h, bloom2};
+	post::tonemap(s, b2, ldr);
+}
+void orc_float_to_half(const float *in, unsigned short *out, long long n)
+{
+	for (long long i = 0; i < n; ++i) out[i] = post::float_to_half(in[i]);
+}
+void orc_half_to_float(const unsigned short *in, float *out, long long n)
+{
+	for (long long i = 0; i < n; ++i) out[i] = post::half_to_float(in[i]);
+}
 
 // Known-answer access to individual library functions (tests/test_oracle_*.py).
 // Returns the number of outputs written, or -1 for an unknown function.

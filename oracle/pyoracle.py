@@ -183,6 +183,32 @@ def render(scene, frame, region=None, step=(1, 1), nthreads=None, stats=False, c
     return out, st, totals
 
 
+def postprocess(scene16):
+    """HDR::process restated: scene16 = [H,W,4] float16 -> (bloom1 f16, bloom2 f16, ldr uint8)."""
+    scene16 = np.ascontiguousarray(scene16, np.float16)
+    H, W, _ = scene16.shape
+    b1 = np.zeros((H, W, 4), np.float16)
+    b2 = np.zeros((H, W, 4), np.float16)
+    ldr = np.zeros((H, W, 4), np.uint8)
+    vp = ctypes.c_void_p
+    lib().orc_postprocess(vp(scene16.ctypes.data), W, H, vp(b1.ctypes.data), vp(b2.ctypes.data), vp(ldr.ctypes.data))
+    return b1, b2, ldr
+
+
+def float_to_half(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(x.shape, np.uint16)
+    lib().orc_float_to_half(ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data), ctypes.c_longlong(x.size))
+    return out
+
+
+def half_to_float(h):
+    h = np.ascontiguousarray(h, np.uint16)
+    out = np.zeros(h.shape, np.float32)
+    lib().orc_half_to_float(ctypes.c_void_p(h.ctypes.data), ctypes.c_void_p(out.ctypes.data), ctypes.c_longlong(h.size))
+    return out
+
+
 def kat(fn, *args, nout=4):
     a = np.zeros(16, np.float32)
     flat = np.asarray(args, np.float32).ravel()

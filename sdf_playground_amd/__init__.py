@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def load_library():
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
     L.sdfr_sync.argtypes = [vp]
     L.sdfr_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.sdfr_postprocess.argtypes = [vp, ci, ci, vp, vp, vp]
     L.sdfr_selftest_math.argtypes = [vp, ci, cf, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
@@ -341,6 +342,15 @@ class SDFRenderer:
                                                  ctypes.c_void_p(out.data_ptr()), fmt))
         return out
 
+    def postprocess(self, scene16, bloom_scratch, out8):
+        """HDR::process on device tensors: scene16/bloom_scratch [H,W,4] float16, out8 [H,W,4] uint8."""
+        H, W = scene16.shape[0], scene16.shape[1]
+        assert scene16.is_cuda and scene16.is_contiguous() and bloom_scratch.is_contiguous() and out8.is_contiguous()
+        assert bloom_scratch.numel() == scene16.numel() == out8.numel()
+        self._check(self._L.sdfr_postprocess(self._h, W, H, ctypes.c_void_p(scene16.data_ptr()), ctypes.c_void_p(bloom_scratch.data_ptr()),
+                                             ctypes.c_void_p(out8.data_ptr())))
+        return out8
+
     def selftestMath(self, what, constant=1.0):
         """Exhaustive GPU check of the fast exact sqrt (what=0) / constant division (what=1); returns mismatches."""
         n = ctypes.c_uint64()
@@ -354,6 +364,36 @@ class SDFRenderer:
         s = Stats()
         self._check(self._L.sdfr_get_stats(self._h, ctypes.byref(s)))
         return s
+
+
+class HDR:
+    """The post-processing stage that consumes the render target.  Mirrors the reference's
+    `class HDR` (Engine/Postprocessing.h:12-43): init / getRenderTarget / process.  The three
+    RGBA16F textures of the reference become two device tensors (render target + one bloom
+    buffer; the second bloom texture is never materialised, see sdfr_post.hip)."""
+
+    def __init__(self, renderer):
+        self._r = renderer
+        self.width = self.height = 0
+
+    def init(self, width, height):
+        import torch
+
+        self.width, self.height = int(width), int(height)
+        self._target = torch.zeros((self.height, self.width, 4), dtype=torch.float16, device="cuda")
+        self._bloom = torch.empty_like(self._target)
+        self._ldr = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device="cuda")
+        return True
+
+    def getRenderTarget(self):
+        """The RGBA16F tensor SDFRenderer.render(..., out=..., fmt=RGBA16F) draws into."""
+        return self._target
+
+    def process(self, scene=None):
+        """bloom + tone map of the render target (or of `scene`, an [H,W,4] float16 cuda
+        tensor) -> [H,W,4] uint8 cuda tensor (R8G8B8A8_UNORM)."""
+        src = self._target if scene is None else scene
+        return self._r.postprocess(src, self._bloom, self._ldr)
 
 
 def assemble_strips_host(width, height, world, gathered):

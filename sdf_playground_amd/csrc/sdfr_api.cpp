@@ -483,6 +483,16 @@ int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, con
 	return SDFR_OK;
 }
 
+int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_rgba16f, void *bloom_scratch_rgba16f, void *out_rgba8)
+{
+	if (!r || !scene_rgba16f || !bloom_scratch_rgba16f || !out_rgba8) return SDFR_ERR_INVALID_ARGUMENT;
+	if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
+	SDFR_HIP(hipSetDevice(r->device));
+	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->stream);
+	if (e != hipSuccess) return hip_fail(r, e, "postprocess launch");
+	return SDFR_OK;
+}
+
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches)
 {
 	if (!r || !mismatches || what < 0 || what > 3) return SDFR_ERR_INVALID_ARGUMENT;

@@ -1,0 +1,65 @@
+"""GPU tier: the bloom + tone-map kernels (sdfr_post.hip) through the C ABI against the
+oracle's restatement of HDR::process: byte-exact LDR image and bit-exact bloom buffer."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    yield r
+    r.close()
+
+
+def _check(renderer, oracle, scene16):
+    import torch
+    import sdf_playground_amd as sp
+
+    H, W, _ = scene16.shape
+    hdr = sp.HDR(renderer)
+    hdr.init(W, H)
+    hdr.getRenderTarget().copy_(torch.from_numpy(scene16))
+    ldr = hdr.process().cpu().numpy()
+    renderer.sync()
+    b1, b2, ref = oracle.postprocess(scene16)
+    assert np.array_equal(hdr._bloom.cpu().numpy().view(np.uint16), b1.view(np.uint16))
+    assert np.array_equal(ldr, ref)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (300, 77), (33, 65), (257, 31), (1, 1), (513, 97)])
+def test_postprocess_random_images(renderer, oracle, size):
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    img = (rng.random((h, w, 4)) ** 3 * 6).astype(np.float16)
+    img[..., 3] = rng.integers(0, 2, (h, w))
+    img[rng.random((h, w)) < 0.02] = [60000, 0, 1e-7, 1]  # large and subnormal halves
+    _check(renderer, oracle, img)
+
+
+def test_postprocess_of_rendered_frame(renderer, oracle):
+    """render (RGBA16F target) -> process, as Application::render does (Application.cpp:274-284)."""
+    import torch
+    import sdf_playground_amd as sp
+
+    W, H = 320, 180
+    renderer.initShader("light_shadows")  # emissive spheres: plenty of bloom
+    renderer.setParameters(0.5)
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7)
+    cam = sp.Camera()
+    cam.SetEye((0, 5, -9))
+    cam.SetLookat((0, 1, 0))
+    cam.SetAspect(W / H)
+    hdr = sp.HDR(renderer)
+    hdr.init(W, H)
+    renderer.render(cam, W, H, out=hdr.getRenderTarget(), fmt=sp.RGBA16F)
+    ldr = hdr.process().cpu().numpy()
+    scene16 = hdr.getRenderTarget().cpu().numpy()
+    _, _, ref = oracle.postprocess(scene16)
+    assert np.array_equal(ldr, ref)
+    assert (ldr[..., :3].max(axis=2) > 200).mean() > 0.002  # something bright is in the picture
