@@ -10,6 +10,7 @@
 #include "sdfr_kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,8 +29,9 @@ struct sdfr_renderer
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int scene = -1;
-	int schedule = SDFR_SCHEDULE_WAVEFRONT;
+	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
 	bool profiling = false;
+	int tile_w_log2 = 3;
 	FrameU U;
 	host::ShaderVariableManager vars;
 	std::vector<std::string> scene_var_slots; // slot k of FrameU::scene_var <- this variable
@@ -109,6 +111,11 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 	if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
 	sdfr_renderer *r = new sdfr_renderer();
 	r->device = device_ordinal;
+	if (const char *t = getenv("SDFR_TILE_W_LOG2")) // developer knob: wave tile shape (3 = 8x8 ... 6 = 64x1)
+	{
+		int v = atoi(t);
+		if (v >= 3 && v <= 6) r->tile_w_log2 = v;
+	}
 	frame_defaults(r->U);
 	// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
 	host::Camera cam;
@@ -398,6 +405,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	RowMap rm;
 	rm.rank = rank;
 	rm.world = world;
+	rm.tile_w_log2 = r->tile_w_log2;
 	rm.local_rows = (int)(sdfr_strip_buffer_pixels(width, height, world) / width);
 	if (world == 1) rm.local_rows = height;
 	const size_t local_pixels = (size_t)rm.local_rows * width;
@@ -434,8 +442,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 
 	SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream));
 	hipError_t e;
-	const size_t tiles = (((size_t)width + 7) / 8) * (((size_t)rm.local_rows + 7) / 8);
-	rc = ensure_workspace(r, tiles * 64);
+	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm));
 	if (rc != SDFR_OK) return rc;
 	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->schedule == SDFR_SCHEDULE_PIXEL)

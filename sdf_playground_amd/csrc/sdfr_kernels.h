@@ -20,6 +20,7 @@ struct RowMap
 {
 	int local_rows;
 	int rank, world;
+	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
 };
 
 enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1 };
@@ -55,5 +56,7 @@ hipError_t launch_postprocess(int width, int height, const void *scene16, void *
 hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream);
 
 int device_cu_count(int device);
+// work items (padded to whole tiles) of a launch: lists and per-pixel state are sized by this
+uint32_t launch_work_items(int width, const RowMap &rm);
 
 } // namespace sdfr

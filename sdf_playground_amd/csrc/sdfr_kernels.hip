@@ -39,7 +39,8 @@ namespace sdfr {
 
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
-// neighbouring pixels (coherent materials, similar step counts).
+// neighbouring pixels (coherent materials, similar step counts).  The tile shape is a launch
+// parameter (RowMap::tile_w_log2): 8x8, 16x4, 32x2 or 64x1.
 struct PixelCoord
 {
 	int px, py;   // in the full frame
@@ -47,11 +48,12 @@ struct PixelCoord
 };
 __device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc)
 {
-	const uint32_t tiles_x = ((uint32_t)U.width + 7u) >> 3;
+	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << tw_log2) - 1u) >> tw_log2;
 	const uint32_t tile = w >> 6, lane = w & 63u;
 	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-	const int px = (int)(tx * 8u + (lane & 7u));
-	const int lrow = (int)(ty * 8u + (lane >> 3));
+	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
+	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
 	const int py = ((lrow >> 3) * rm.world + rm.rank) * 8 + (lrow & 7);
 	if (py >= U.height) return false;
@@ -66,12 +68,14 @@ __device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, 
 	px = (int)(pid - lrow * (uint32_t)U.width);
 	py = (int)(((lrow >> 3) * (uint32_t)rm.world + (uint32_t)rm.rank) * 8u + (lrow & 7u));
 }
-static uint32_t work_items(const FrameU &U, const RowMap &rm)
+uint32_t launch_work_items(int width, const RowMap &rm)
 {
-	const uint32_t tiles_x = ((uint32_t)U.width + 7u) >> 3;
-	const uint32_t tiles_y = ((uint32_t)rm.local_rows + 7u) >> 3;
+	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
+	const uint32_t tiles_x = ((uint32_t)width + (1u << tw_log2) - 1u) >> tw_log2;
+	const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
 	return tiles_x * tiles_y * 64u;
 }
+static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_work_items(U.width, rm); }
 
 __device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid, vec4 c)
 {
