@@ -27,24 +27,31 @@ struct Census
 {
 	unsigned long long flops, transc;
 	// arguments outside the domain on which the GPU kernels' fast exact sequences are valid
-	// (sdf_playground_amd/csrc/sdfr_math.h: sqrt1, div_c); must stay 0 on every workload
-	unsigned long long sqrt_out_of_domain, divc_out_of_domain; // (the latter also counts fast-plane heights)
+	// (sdf_playground_amd/csrc/sdfr_math.h: sqrt1, div_c).  "near": negative, -0 or tiny
+	// arguments -- must stay 0 on every workload.  "far": overflowed (+inf / NaN / > 2^40)
+	// arguments, which only a ray that has escaped the scene by ~1e18 units can produce
+	// (DESIGN.md 1.3 explains why their values are never used).
+	unsigned long long sqrt_out_of_domain, divc_out_of_domain; // near field
+	unsigned long long far_field;
 };
-inline Census &census() { static thread_local Census c = {0, 0, 0, 0}; return c; }
+inline Census &census() { static thread_local Census c = {0, 0, 0, 0, 0}; return c; }
 inline void census_check_sqrt(float a)
 {
 	uint32_t u = dm::f2u(a);
-	if (!(u == 0u || (a >= 0x1p-96f && a <= 3.402823466e+38f))) census().sqrt_out_of_domain++;
+	if (a != a || a > 3.402823466e+38f) census().far_field++;
+	else if (!(u == 0u || a >= 0x1p-96f)) census().sqrt_out_of_domain++;
 }
 inline void census_check_divc(float a)
 {
 	float m = fabsf(a);
-	if (!(m == 0.f || (m >= 0x1p-100f && m <= 0x1p100f))) census().divc_out_of_domain++;
+	if (a != a || m > 0x1p100f) census().far_field++;
+	else if (!(m == 0.f || m >= 0x1p-100f)) census().divc_out_of_domain++;
 }
 inline void census_check_plane(float a, float c)
 {
 	float m = fabsf(a);
-	if (!(m == 0.f || (m >= 0x1p-60f && m <= 0x1p40f)) || !(c >= 1e-20f && c <= 2.f))
+	if (a != a || m > 0x1p40f) census().far_field++;
+	else if (!(m == 0.f || m >= 0x1p-60f) || !(c >= 1e-20f && c <= 2.f))
 	{
 		census().divc_out_of_domain++;
 		if (getenv("ORC_CENSUS_VERBOSE")) fprintf(stderr, "plane out of domain: height %a (%g) denom %a\n", a, a, c);

@@ -16,6 +16,7 @@
 #include "host.h"
 #include "postprocess.h"
 #include "scenes.h"
+#include "scenes2.h"
 
 #include <atomic>
 #include <cstdio>
@@ -75,6 +76,27 @@ const std::vector<SceneEntry> &scenes()
 			{"xpos", "ypos", "zpos", "mixing"}, &ps_main<SceneLense>},
 		{"gems", "", {}, &ps_main<SceneGems>},
 		{"light_shadows", "", {}, &ps_main<SceneLightShadows>},
+		{"cube",
+			"VAR_size(min = 0.2, max = 2, start = 1, step = 0.2) VAR_xpos(min = -2, max = 2, start = 0, step = 0.1) "
+			"VAR_ypos(min = -2, max = 2, start = 0, step = 0.1) VAR_zpos(min = -2, max = 2, start = 0, step = 0.1) "
+			"VAR_red(min = 0, max = 1, start = 0.9, step = 0.05) VAR_green(min = 0, max = 1, start = 0.7, step = 0.05) "
+			"VAR_blue(min = 0, max = 1, start = 0.2, step = 0.05)",
+			{"size", "xpos", "ypos", "zpos", "red", "green", "blue"}, &ps_main<SceneCube>},
+		{"gyroid", "", {}, &ps_main<SceneGyroid>},
+		{"basic_transparency", "", {}, &ps_main<SceneBasicTransparency>},
+		{"basic_clouds", "VAR_offset(min = -5, max = 5, step = 0.05)", {"offset"}, &ps_main<SceneBasicClouds>},
+		{"coordinate_material",
+			"VAR_boxoffset(min = 0, max = 2, step = 0.1, start = 2) VAR_spherical(min = 0, max = 1, step = 1, start = 0) "
+			"VAR_thres(min=0,max=1,step=0.05, start=0.4)",
+			{"boxoffset", "spherical", "thres"}, &ps_main<SceneCoordinateMaterial>},
+		{"distortion", "", {}, &ps_main<SceneDistortion>},
+		{"table", "", {}, &ps_main<SceneTable>},
+		{"sierpinski", "", {}, &ps_main<SceneSierpinski>},
+		{"neon",
+			"VAR_r1(min = 0.2, max = 2, start = 1) VAR_r2(min = 0.005, max = 0.1, start = 0.01) VAR_spacing(min = 0.01, max = 0.2, start = 0.1) "
+			"VAR_red(min = 0, max = 3, start = 0.1, step = 0.05) VAR_green(min = 0, max = 3, start = 1.0, step = 0.05) "
+			"VAR_blue(min = 0, max = 3, start = 0.2, step = 0.05)",
+			{"r1", "r2", "spacing", "red", "green", "blue"}, &ps_main<SceneNeon>},
 	};
 	return table;
 }
@@ -294,14 +316,15 @@ int orc_render(const char *scene, const orc_frame *frame, float *out_rgba, unsig
 
 #ifdef ORACLE_CENSUS
 // flop census of the calling thread (render with nthreads = 1): {flops, transcendentals}
-void orc_census_reset() { census() = Census{0, 0, 0, 0}; }
-// {flops, transcendentals, sqrt arguments out of domain, constant-division numerators out of domain}
+void orc_census_reset() { census() = Census{0, 0, 0, 0, 0}; }
+// {flops, transcendentals, near-field sqrt / division arguments out of domain, far-field (overflowed) arguments}
 void orc_census_get(unsigned long long *out4)
 {
 	out4[0] = census().flops;
 	out4[1] = census().transc;
 	out4[2] = census().sqrt_out_of_domain;
 	out4[3] = census().divc_out_of_domain;
+	out4[4] = census().far_field;
 }
 #endif
 

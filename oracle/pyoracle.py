@@ -260,10 +260,12 @@ def census(scene, frame, step=(1, 1), region=None):
     L = lib(census=True)
     L.orc_census_reset()
     out, _, totals = render(scene, frame, region=region, step=step, nthreads=1, census=True)
-    c = np.zeros(4, np.uint64)
+    c = np.zeros(5, np.uint64)
     L.orc_census_get(c.ctypes.data_as(ctypes.c_void_p))
     census.last_domain_violations = (int(c[2]), int(c[3]))
+    census.last_far_field = int(c[4])
     return out, totals, int(c[0]), int(c[1])
 
 
 census.last_domain_violations = (0, 0)
+census.last_far_field = 0

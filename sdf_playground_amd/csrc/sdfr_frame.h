@@ -56,6 +56,7 @@ struct SurfacePoint
 	vec3 pos, dir;
 	float camera_distance;
 	vec3 right_off, bottom_off; // pixel footprint per unit of distance
+	vec3 normal;                // MaterialInput.obj_normal: the geometric normal at the hit
 };
 
 // MaterialOutput of the scene ABI (sdf_structs.hlsl:66-110), defaults of pshader_sdf.hlsl:338-351

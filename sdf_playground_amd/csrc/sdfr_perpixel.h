@@ -8,6 +8,7 @@
 #pragma once
 #include "sdfr_pixel.h"
 #include "sdfr_scenes.h"
+#include "sdfr_scenes2.h"
 
 namespace sdfr {
 
@@ -119,7 +120,9 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 
 // scene registry: X(index, SceneType)
 #define SDFR_FOR_EACH_SCENE(X) \
-	X(0, SceneFastSphere) X(1, SceneCubeSea) X(2, SceneLabyrinth) X(3, SceneFractal) X(4, SceneLense) X(5, SceneGems) X(6, SceneLightShadows)
-enum { SDFR_SCENE_COUNT = 7 };
+	X(0, SceneFastSphere) X(1, SceneCubeSea) X(2, SceneLabyrinth) X(3, SceneFractal) X(4, SceneLense) X(5, SceneGems) X(6, SceneLightShadows) \
+	X(7, SceneCube) X(8, SceneGyroid) X(9, SceneBasicTransparency) X(10, SceneBasicClouds) X(11, SceneCoordinateMaterial) \
+	X(12, SceneDistortion) X(13, SceneTable) X(14, SceneSierpinski) X(15, SceneNeon)
+enum { SDFR_SCENE_COUNT = 16 };
 
 } // namespace sdfr

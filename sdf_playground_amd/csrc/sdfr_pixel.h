@@ -279,6 +279,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 	sp.camera_distance = hit.t;
 	sp.right_off = px.right_ray;
 	sp.bottom_off = px.bottom_ray;
+	sp.normal = hit.normal;
 
 	Material m = default_material(U, hit.pos);
 	map_material<Scene, DBG>(U, F, sp, m);

@@ -1,0 +1,502 @@
+// sdfr_scenes2.h -- nine more ahead-of-time scene functors (device code, host-compilable):
+// cube, gyroid, basic_transparency, basic_clouds, coordinate_material, distortion, table,
+// sierpinski, neon (Engine/shader/scenes/sdf_scene_<name>.hlsl).  Same functor interface
+// as sdfr_scenes.h.
+#pragma once
+#include "sdfr_scenes.h"
+
+namespace sdfr {
+
+// =========================================================================================
+struct SceneCube
+{
+	static const char *name() { return "cube"; }
+	enum { V_SIZE = 0, V_X, V_Y, V_Z, V_RED, V_GREEN, V_BLUE };
+	static const char *variables()
+	{
+		return "VAR_size(min = 0.2, max = 2, start = 1, step = 0.2) VAR_xpos(min = -2, max = 2, start = 0, step = 0.1) "
+			   "VAR_ypos(min = -2, max = 2, start = 0, step = 0.1) VAR_zpos(min = -2, max = 2, start = 0, step = 0.1) "
+			   "VAR_red(min = 0, max = 1, start = 0.9, step = 0.05) VAR_green(min = 0, max = 1, start = 0.7, step = 0.05) "
+			   "VAR_blue(min = 0, max = 1, start = 0.2, step = 0.05)";
+	}
+	static void prepare(FrameU &) {}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	static SDF_HD float cube(const FrameU &U, vec3 p)
+	{
+		const vec3 c = V3(U.scene_var[V_X], U.scene_var[V_Y], U.scene_var[V_Z]);
+		return sd_box(p - V3(0.f, 1.f, 0.f) - c, V3s(U.scene_var[V_SIZE]));
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		return min1(d, cube(U, p));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(cube(U, sp.pos)))
+		{
+			m.diffuse = V4(U.scene_var[V_RED], U.scene_var[V_GREEN], U.scene_var[V_BLUE], 1.f);
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneGyroid
+{
+	static const char *name() { return "gyroid"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { int unused; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
+	// a gyroid shell clipped to the unit cube; no floor in this scene
+	static SDF_HD float shape(vec3 p)
+	{
+		const vec3 q = p * 7.f;
+		const vec2 sx = sincos1(q.x), sy = sincos1(q.y), sz = sincos1(q.z);
+		float g = dot(V3(sx.x, sy.x, sz.x), V3(sz.y, sx.y, sy.y)) / 14.f;
+		g = abs1(g) - 0.01f;
+		return max1(g, sd_box(p, V3(1.f, 1.f, 1.f)));
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &, vec3 p, vec3, bool) { return min1(3e38f, shape(p)); }
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		if (on_surface(shape(sp.pos)))
+		{
+			m.diffuse.x = 0.9f;
+			m.diffuse.y = 0.7f;
+			m.diffuse.z = 0.2f;
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneBasicTransparency
+{
+	static const char *name() { return "basic_transparency"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	static SDF_HD float pane(vec3 p, float z) { return sd_box(p - V3(0.f, 2.f, z), V3(1.f, 1.f, 0.1f)); }
+	// a ray continuing through a pane ignores the pane it just left (OBJECT_TRANSPARENT)
+	struct RayInv { GroundInv ground; bool skip1, skip2, skip3; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		r.skip1 = f.has_transparent && pane(f.last_transparent_pos, -1.f) < SDFR_DIST_EPS;
+		r.skip2 = f.has_transparent && pane(f.last_transparent_pos, 0.f) < SDFR_DIST_EPS;
+		r.skip3 = f.has_transparent && pane(f.last_transparent_pos, 1.f) < SDFR_DIST_EPS;
+		return r;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		const float b1 = pane(p, -1.f), b2 = pane(p, 0.f), b3 = pane(p, 1.f);
+		d = R.skip1 ? d : min1(d, b1);
+		d = R.skip2 ? d : min1(d, b2);
+		d = R.skip3 ? d : min1(d, b3);
+		return d;
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(pane(sp.pos, -1.f)))
+			m.diffuse = V4(0.9f, 0.9f, 0.f, 0.3f);
+		else if (on_surface(pane(sp.pos, 0.f)))
+			m.diffuse = V4(0.f, 0.9f, 0.9f, 0.3f);
+		else if (on_surface(pane(sp.pos, 1.f)))
+			m.diffuse = V4(0.9f, 0.f, 0.9f, 0.3f);
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneBasicClouds
+{
+	static const char *name() { return "basic_clouds"; }
+	static const char *variables() { return "VAR_offset(min = -5, max = 5, step = 0.05)"; }
+	static void prepare(FrameU &) {}
+	static SDF_HD float slab(vec3 p) { return sd_box(p - V3(0.f, 5.f, 0.f), V3(2.f, 0.5f, 2.f)); }
+	struct RayInv { GroundInv ground; bool skip_cloud; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		r.skip_cloud = f.has_transparent && slab(f.last_transparent_pos) < SDFR_DIST_EPS;
+		return r;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		const float c = slab(p);
+		return R.skip_cloud ? d : min1(d, c);
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(slab(sp.pos)))
+		{
+			// density sampled at five points along the view ray
+			const vec3 cloud_pos = sp.pos - V3(0.f, 5.f, 0.f);
+			float thickness = 0.f + U.scene_var[0];
+			for (int i = 0; i < 5; ++i)
+				thickness = thickness + turbulence3(cloud_pos + sp.dir * 0.5f * (float)i);
+			thickness = sat1(thickness);
+			const float c = 1.f - thickness * 0.2f;
+			m.diffuse = V4(c, c, c, thickness);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	{
+		if (i != 0) return false;
+		L.pos = V3(-1.f, -4.f, 1.5f);
+		L.directional = true;
+		L.color = V3(1.f, 1.f, 1.f);
+		L.extend = 0.f;
+		L.falloff = 0.f;
+		return true;
+	}
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneCoordinateMaterial
+{
+	static const char *name() { return "coordinate_material"; }
+	static const char *variables()
+	{
+		return "VAR_boxoffset(min = 0, max = 2, step = 0.1, start = 2) VAR_spherical(min = 0, max = 1, step = 1, start = 0) "
+			   "VAR_thres(min=0,max=1,step=0.05, start=0.4)";
+	}
+	static void prepare(FrameU &) {}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	static SDF_HD float shape(const FrameU &U, vec3 p)
+	{
+		const float sphere = sd_sphere(p - V3(0.f, 2.f, 0.f), 2.f);
+		const float box = sd_box(p - V3(-1.f, 3.f + U.scene_var[0], -1.f), V3s(1.f));
+		return max1(sphere, -box);
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		return min1(d, shape(U, p));
+	}
+	static SDF_HD vec3 to_spherical(vec3 p)
+	{
+		return V3(length(p), atan21(p.y, length(V2(p.x, p.z))), atan21(p.z, p.x));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(shape(U, sp.pos)))
+		{
+			vec3 pos = (sp.pos - V3(0.f, 2.f, 0.f)) * 2.f;
+			vec3 norm = sp.normal;
+			if (U.scene_var[1] > 0.5f)
+			{
+				// grid in (r, theta, phi); the normal is transformed by a finite difference
+				const vec3 sph = to_spherical(pos);
+				const vec3 off = to_spherical(pos + norm * 0.01f);
+				norm = normalize(off - sph);
+				pos = sph * V3(1.f, 8.f / SDFR_PI, 8.f / SDFR_PI);
+			}
+			const float sel = mat_coordinate_grid(pos, norm, 0.02f);
+			const bool on_line = sel > U.scene_var[2];
+			m.diffuse.x = on_line ? 1.f : 0.8f;
+			m.diffuse.y = on_line ? 0.f : 0.8f;
+			m.diffuse.z = on_line ? 0.f : 0.8f;
+			set_rgb(m.specular, 0.25f);
+			m.specular.w = 100.f;
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneDistortion
+{
+	static const char *name() { return "distortion"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	// displace a distance field by a height function with known Lipschitz bound
+	static SDF_HD float distort(float obj, float val, float lip, float h)
+	{
+		const float actual = (obj - val) / sqrt1(1.f + lip * lip);
+		return lerp1(actual, obj - h, sat1(obj / h - 1.f));
+	}
+	struct Wall { float box, val, noise; };
+	static SDF_HD Wall wall(vec3 p)
+	{
+		Wall w;
+		const vec3 bp = p - V3(0.f, 1.5f, 0.f);
+		const float scaled = bp.y * 2.5f - 1.25f;
+		const float index = scaled - floor1(scaled);
+		const float offset = step1(0.5f, index);
+		const float val_x = 1.f - pow1(sat1(sin1((bp.x + offset * 0.2f) * SDFR_PI * 5.f)), 10.f);
+		const float val_y = 1.f - pow1(abs1(sin1(bp.y * SDFR_PI * 5.f)), 10.f);
+		w.noise = turbulence3(bp * 7.5f);
+		float v = min1(val_x, val_y);
+		v = lerp1(v * 0.8f, v, w.noise);
+		w.val = v;
+		const float height = 0.025f, lip = 2.f;
+		w.box = distort(sd_box(bp, V3(1.f, 1.f, 0.1f)), v * height, lip * height, height);
+		return w;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		return min1(d, wall(p).box);
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		const Wall w = wall(sp.pos);
+		if ((w.box - 0.1f) < SDFR_DIST_EPS)
+		{
+			const vec3 brick = lerp(V3(0.5f, 0.1f, 0.1f), V3(0.8f, 0.2f, 0.2f), w.noise);
+			const vec3 c = w.val < 0.15f ? V3(0.5f, 0.5f, 0.5f) : brick;
+			m.diffuse.x = c.x;
+			m.diffuse.y = c.y;
+			m.diffuse.z = c.z;
+			set_rgb(m.specular, 0.125f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneTable
+{
+	static const char *name() { return "table"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	struct Objects { float plate, legs, vase; vec3 p; };
+	static SDF_HD Objects eval_objects(vec3 pos)
+	{
+		const float leg_width = 0.05f, leg_height = 0.7f, leg_distance = 1.f, plate_size = 1.2f, plate_height = 0.0175f;
+		Objects o;
+		vec3 p = pos;
+		p.y = p.y - 0.4f;
+		o.p = p;
+		o.legs = sd_box(abs(p) - V3(leg_distance, leg_height * 0.5f, leg_distance), V3(leg_width, leg_height * 0.5f, leg_width));
+		o.plate = sd_box(p - V3(0.f, leg_height + 0.025f, 0.f), V3(plate_size, plate_height, plate_size)) - 0.025f;
+		// a vase of three smoothly merged spheres, hollowed out
+		const float s1 = sd_sphere(p - V3(0.f, leg_height + 0.15f, 0.f), 0.2f);
+		const float s2 = sd_sphere(p - V3(0.f, leg_height + 0.45f, 0.f), 0.17f);
+		const float s3 = sd_sphere(p - V3(0.f, leg_height + 0.72f, 0.f), 0.15f);
+		const float cut_top = sd_plane(p - V3(0.f, leg_height + 0.615f, 0.f), V3(0.f, 1.f, 0.f));
+		const float cut_low = sd_plane(p - V3(0.f, leg_height + 0.1f, 0.f), V3(0.f, -1.f, 0.f));
+		const float body = max1(op_smin(op_smin(s1, s2, 0.05f), s3, 0.025f), cut_low);
+		o.vase = max1(max1(body, cut_top), -body - 0.01f);
+		return o;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		const Objects o = eval_objects(p);
+		d = min1(d, o.plate);
+		d = min1(d, o.legs);
+		return min1(d, o.vase);
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		const Objects o = eval_objects(sp.pos);
+		if (on_surface(o.plate))
+		{
+			const float plank = floor1((o.p.x + 1.25f) * 4.f) / 8.f;
+			m.mpos = o.p + V3(o.p.z * 0.2f, plank, 0.f);
+			m.id = MAT_WOOD;
+		}
+		else if (on_surface(o.legs))
+		{
+			m.mpos = V3(o.p.x, o.p.z, o.p.y);
+			m.id = MAT_WOOD;
+		}
+		else if (on_surface(o.vase))
+		{
+			m.mpos = o.p * 4.f;
+			m.id = MAT_MARBLE_DARK;
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneSierpinski
+{
+	static const char *name() { return "sierpinski"; }
+	static const char *variables() { return ""; }
+	static void prepare(FrameU &) {}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	// fold towards the nearest of four tetrahedron vertices, ten times
+	static SDF_HD float tetra(vec3 p)
+	{
+		const vec3 a1 = V3(0.f, 1.f, 0.f), a2 = V3(-0.7f, 0.f, -0.5f), a3 = V3(0.7f, 0.f, -0.5f), a4 = V3(0.f, 0.f, 0.7f);
+		const float scale = 2.f;
+#pragma unroll
+		for (int it = 0; it < 10; ++it)
+		{
+			vec3 c = a1;
+			float best = length(p - a1);
+			float d = length(p - a2);
+			if (d < best) { c = a2; best = d; }
+			d = length(p - a3);
+			if (d < best) { c = a3; best = d; }
+			d = length(p - a4);
+			if (d < best) { c = a4; best = d; }
+			p = scale * p - c * (scale - 1.f);
+		}
+		return length(p) / pow1(scale, 10.f) - 0.002f;
+	}
+	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		return min1(d, tetra(p - V3(0.f, 1.f, 0.f)));
+	}
+	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(tetra(sp.pos - V3(0.f, 1.f, 0.f))))
+		{
+			m.diffuse.x = 0.9f;
+			m.diffuse.y = 0.7f;
+			m.diffuse.z = 0.2f;
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+// =========================================================================================
+struct SceneNeon
+{
+	static const char *name() { return "neon"; }
+	static const char *variables()
+	{
+		return "VAR_r1(min = 0.2, max = 2, start = 1) VAR_r2(min = 0.005, max = 0.1, start = 0.01) VAR_spacing(min = 0.01, max = 0.2, start = 0.1) "
+			   "VAR_red(min = 0, max = 3, start = 0.1, step = 0.05) VAR_green(min = 0, max = 3, start = 1.0, step = 0.05) "
+			   "VAR_blue(min = 0, max = 3, start = 0.2, step = 0.05)";
+	}
+	enum { SU_MIRROR_S = 0, SU_MIRROR_C = 1 };
+	static void prepare(FrameU &U)
+	{
+		const vec2 sc = sincos1(0.3f); // the mirror's fixed yaw
+		U.su[SU_MIRROR_S] = sc.x;
+		U.su[SU_MIRROR_C] = sc.y;
+	}
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+	// thin rings at quantised latitudes of a sphere
+	static SDF_HD float ring_sphere(vec3 p, float spacing, float r1, float r2)
+	{
+		vec3 hp = normalize(p) * r1;
+		const float y = hp.y;
+		const float x = length(V2(hp.x, hp.z));
+		float angle = atan21(y, x);
+		angle = rne1(angle / spacing) * spacing;
+		const vec2 sc = sincos1(angle);
+		hp.y = sc.x / sc.y * x; // tan(angle) * x
+		hp = normalize(hp) * r1;
+		return length(p - hp) - r2;
+	}
+	struct Objects { float rings, mirror, border; };
+	static SDF_HD Objects eval_objects(const FrameU &U, vec3 p)
+	{
+		Objects o;
+		o.rings = ring_sphere(p - V3(0.f, 2.f, 0.f), U.scene_var[2], U.scene_var[0], U.scene_var[1]);
+		vec3 mp = p - V3(0.f, 2.f, 2.75f);
+		const vec2 r = rot2(V2(mp.x, mp.z), U.su[SU_MIRROR_S], U.su[SU_MIRROR_C]);
+		mp = V3(r.x, mp.y, r.y);
+		o.mirror = sd_box(mp, V3(1.f, 1.7f, 0.05f));
+		o.border = sd_box(mp, V3(1.05f, 1.75f, 0.04f));
+		return o;
+	}
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		const Objects o = eval_objects(U, p);
+		d = min1(d, o.rings);
+		d = min1(d, o.mirror);
+		return min1(d, o.border);
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		const Objects o = eval_objects(U, sp.pos);
+		if (on_surface(o.rings))
+		{
+			const vec3 c = V3(U.scene_var[3], U.scene_var[4], U.scene_var[5]);
+			m.emissive = c;
+			const vec3 h = c / 2.f;
+			m.diffuse.x = h.x;
+			m.diffuse.y = h.y;
+			m.diffuse.z = h.z;
+			set_rgb(m.specular, 0.5f);
+		}
+		else if (on_surface(o.mirror))
+		{
+			m.reflection = V3s(0.8f);
+			set_rgb(m.specular, 0.1f);
+		}
+		else if (on_surface(o.border))
+		{
+			m.diffuse.x = 0.5f;
+			m.diffuse.y = 0.5f;
+			m.diffuse.z = 0.5f;
+			set_rgb(m.specular, 0.5f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
+
+} // namespace sdfr

@@ -108,3 +108,7 @@ def test_fast_math_domain_is_respected_on_all_scenes(oracle):
         f.width, f.height = 40, 40
         oracle.census(gu.scene_of(path), f)
         assert oracle.census.last_domain_violations == (0, 0), path
+        # overflowed arguments need a ray that escaped by ~1e18 units: only basic_clouds' transparency
+        # continuation rays, which see nothing but the fast floor plane, do that
+        if gu.scene_of(path) != "basic_clouds":
+            assert oracle.census.last_far_field == 0, path

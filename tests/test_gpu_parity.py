@@ -28,6 +28,15 @@ def _cameras(oracle):
         "lense": ("lookat", (7 * math.sin(-0.3), 0.5, 7 * math.cos(-0.3)), (0, 0, 0)),
         "gems": ("lookat", (2.5 * math.cos(TH), 2, 2.5 * math.sin(TH)), (0, 1, 0)),
         "light_shadows": ("lookat", (0, 5, -9), (0, 1, 0)),
+        "cube": ("lookat", (2.5, 2.5, -3), (0, 1, 0)),
+        "gyroid": ("lookat", (1.8, 1.6, -2.2), (0, 0, 0)),
+        "basic_transparency": ("lookat", (2.0, 2.5, -4), (0, 2, 0)),
+        "basic_clouds": ("lookat", (0, 2, -8), (0, 4, 0)),
+        "coordinate_material": ("lookat", (3, 4, -5), (0, 2, 0)),
+        "distortion": ("lookat", (0.8, 1.8, -2.5), (0, 1.5, 0)),
+        "table": ("lookat", (2, 2, -3), (0, 1, 0)),
+        "sierpinski": ("lookat", (1.2, 1.6, -2.2), (0, 1.2, 0)),
+        "neon": ("lookat", (-2, 2.5, -3.5), (0, 2, 1)),
     }, fovy, asp
 
 
@@ -87,7 +96,8 @@ def _compare(renderer, oracle, scene, f, schedule):
     return np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 
-SCENES = ["fast_sphere", "cube_sea", "labyrinth", "fractal", "lense", "gems", "light_shadows"]
+SCENES = ["fast_sphere", "cube_sea", "labyrinth", "fractal", "lense", "gems", "light_shadows", "cube", "gyroid", "basic_transparency",
+          "basic_clouds", "coordinate_material", "distortion", "table", "sierpinski", "neon"]
 
 
 @pytest.mark.parametrize("schedule", [0, 1], ids=["wavefront", "pixel"])
@@ -124,6 +134,12 @@ def test_variables_and_debug_views(renderer, oracle):
     f = _setup(renderer, oracle, "fractal", 0.0, variables=dict(show_objects=0.0, debug_nx=0.3, debug_ny=1.0, debug_y=0.2))
     for schedule in (0, 1):
         assert _compare(renderer, oracle, "fractal", f, schedule)
+    f = _setup(renderer, oracle, "coordinate_material", 0.0, variables=dict(spherical=1.0, thres=0.3, boxoffset=0.5))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "coordinate_material", f, schedule)
+    f = _setup(renderer, oracle, "neon", 0.0, variables=dict(r1=1.4, spacing=0.15, red=2.0))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "neon", f, schedule)
     renderer.initShader("lense")  # reloading a scene resets its variables (Application.cpp:237)
     assert renderer.getVariableMap()["mixing"].value == 0.5
 

@@ -27,6 +27,15 @@ CAMS = {
     "lense": ("lookat", (7 * math.sin(-0.3), 0.5, 7 * math.cos(-0.3)), (0, 0, 0)),
     "gems": ("lookat", (2.5 * math.cos(TH), 2, 2.5 * math.sin(TH)), (0, 1, 0)),
     "light_shadows": ("lookat", (0, 5, -9), (0, 1, 0)),
+    "cube": ("lookat", (2.5, 2.5, -3), (0, 1, 0)),
+    "gyroid": ("lookat", (1.8, 1.6, -2.2), (0, 0, 0)),
+    "basic_transparency": ("lookat", (2.0, 2.5, -4), (0, 2, 0)),
+    "basic_clouds": ("lookat", (0, 2, -8), (0, 4, 0)),
+    "coordinate_material": ("lookat", (3, 4, -5), (0, 2, 0)),
+    "distortion": ("lookat", (0.8, 1.8, -2.5), (0, 1.5, 0)),
+    "table": ("lookat", (2, 2, -3), (0, 1, 0)),
+    "sierpinski": ("lookat", (1.2, 1.6, -2.2), (0, 1.2, 0)),
+    "neon": ("lookat", (-2, 2.5, -3.5), (0, 2, 1)),
 }
 FIELDS = ["stime", "width", "height", "iter_count", "bounce_count", "ray_count", "light_count", "range", "max_cost_default",
           "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects"]
