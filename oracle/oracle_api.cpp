@@ -17,6 +17,8 @@
 #include "postprocess.h"
 #include "scenes.h"
 #include "scenes2.h"
+#include "scenes3.h"
+#include "scenes4.h"
 
 #include <atomic>
 #include <cstdio>
@@ -97,6 +99,17 @@ const std::vector<SceneEntry> &scenes()
 			"VAR_red(min = 0, max = 3, start = 0.1, step = 0.05) VAR_green(min = 0, max = 3, start = 1.0, step = 0.05) "
 			"VAR_blue(min = 0, max = 3, start = 0.2, step = 0.05)",
 			{"r1", "r2", "spacing", "red", "green", "blue"}, &ps_main<SceneNeon>},
+		{"fractal2", "VAR_slider(min = -5, max = 5, step = 0.01, start = 0)", {"slider"}, &ps_main<SceneFractal2>},
+		{"shell", "", {}, &ps_main<SceneShell>},
+		{"spiral", "", {}, &ps_main<SceneSpiral>},
+		{"terrain", "VAR_levels(min=1, max=10, step=1, start=2)", {"levels"}, &ps_main<SceneTerrain>},
+		{"tiling",
+			"VAR_m1(min = -1, max = 3, step = 0.1, start = 1) VAR_m2(min = -1, max = 3, step = 0.1, start = 0) "
+			"VAR_width(min = 0.1, max = 0.5, step = 0.05, start = 0.4) VAR_run_length(min = 1, max = 10, step = 1, start = 4) "
+			"VAR_run_flip(min = 1, max = 10, step = 1, start = 2) VAR_flip_chance(min = 0, max = 1, steps = 0.05) "
+			"VAR_truchet_width(min = 0, max = 0.2, step = 0.01)",
+			{"m1", "m2", "width", "run_length", "run_flip", "flip_chance", "truchet_width"}, &ps_main<SceneTiling>},
+		{"tree", "", {}, &ps_main<SceneTree>},
 	};
 	return table;
 }

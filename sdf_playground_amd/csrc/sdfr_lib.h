@@ -266,6 +266,90 @@ SDF_HD vec3 sky_color(vec3 dir, float rot_s, float rot_c)
 	vec3 sky = lerp(blue, white, n) * 1.2f;
 	return lerp(V3s(0.25f), sky, sat1(dir.y * 8.f + 0.125f));
 }
+// the same sky with the cloud mix remapped to n * scale + bias (scenes with their own sky)
+SDF_HD vec3 sky_color_mix(vec3 dir, float rot_s, float rot_c, float scale, float bias)
+{
+	vec2 r = rot2(V2(dir.x, dir.z), rot_s, rot_c);
+	dir.x = r.x;
+	dir.z = r.y;
+	float n = turbulence3(dir * V3(1.f, 6.f, 1.f) * 2.5f);
+	vec3 blue = V3(43.f, 164.f, 247.f) / 255.f;
+	vec3 white = V3(212.f, 224.f, 238.f) / 255.f;
+	vec3 sky = lerp(blue, white, n * scale + bias) * 1.2f;
+	return lerp(V3s(0.25f), sky, sat1(dir.y * 8.f + 0.125f));
+}
+
+// ---- 2-D tilings used as materials (sdf_materials.hlsl:33-140) ------------------------------
+SDF_HD uint32_t cell_hash_key(vec2 cell, float salt) { return (uint32_t)ftoi1(cell.x + cell.y * 217.743f + salt); }
+SDF_HD vec2 voronoi_site(vec2 cell)
+{
+	float x = pcg_hashf((uint32_t)ftoi1(cell.x + cell.y * 217.743f));
+	float y = pcg_hashf(cell_hash_key(cell, 2475.235f));
+	return V2(x, y) * 2.f - 1.f;
+}
+// returns (id.x, id.y, distance to the nearest site, distance to the nearest cell edge)
+SDF_HD vec4 voronoi(vec2 uv, float max_offset)
+{
+	const vec2 cell = floor(uv);
+	const vec2 local = (uv - cell) - 0.5f;
+	float best = 10.f, edge = 10.f;
+	vec2 best_id = V2(0.f, 0.f), best_site = V2(0.f, 0.f);
+	for (int x = -1; x < 2; ++x)
+		for (int y = -1; y < 2; ++y)
+		{
+			const vec2 off = V2((float)x, (float)y);
+			const vec2 id = cell + off;
+			const vec2 site = off + voronoi_site(id) * max_offset;
+			const float l = length(site - local);
+			if (l < best) { best = l; best_id = id; best_site = site; }
+		}
+	for (int x = -1; x < 2; ++x)
+		for (int y = -1; y < 2; ++y)
+		{
+			const vec2 off = V2((float)x, (float)y);
+			const vec2 site = off + voronoi_site(cell + off) * max_offset;
+			const vec2 mid = (site + best_site) * 0.5f;
+			// for the nearest site itself this is 0 * inf = NaN, which min drops
+			edge = min1(abs1(dot(normalize(best_site - mid), local - mid)), edge);
+		}
+	return V4(best_id.x, best_id.y, best, edge);
+}
+// quarter-circle Truchet tiles; returns (cell.x, cell.y, across-band u, along-band v) or miss_uv
+SDF_HD vec4 truchet_band(vec2 uv, float chance, float width, vec2 miss_uv)
+{
+	const vec2 cell = floor(uv);
+	vec2 local = (uv - cell) - 0.5f;
+	const float flip3 = step1(frac1((cell.x + cell.y) * 0.5f + 0.25f), 0.5f) * 2.f - 1.f;
+	const float flip2 = step1(pcg_hashf((uint32_t)ftoi1(cell.x + cell.y * 217.743f)), chance) * 2.f - 1.f;
+	local.y = local.y * flip2;
+	const float flip1 = step1(local.y, local.x) * 2.f - 1.f;
+	local = local * flip1;
+	local = local + V2(-0.5f, 0.5f);
+	const float len = length(local);
+	if (abs1(len - 0.5f) < width)
+	{
+		float a = (len - 0.5f + width) / (2.f * width);
+		float b = atan21(local.y, -local.x) / (3.1415926f * 0.5f);
+		a = lerp1(1.f - a, a, flip2 * flip3 * 0.5f + 0.5f);
+		b = lerp1(1.f - b, b, flip3 * 0.5f + 0.5f);
+		return V4(cell.x, cell.y, a, b);
+	}
+	return V4(cell.x, cell.y, miss_uv.x, miss_uv.y);
+}
+// woven bands; returns (cell.x, cell.y, position within the band) or miss_uv
+SDF_HD vec4 braid(vec2 uv, float width, float run_length, float run_flip, vec2 miss_uv)
+{
+	const vec2 cell = floor(uv);
+	vec2 local = (uv - cell) - 0.5f;
+	const float t = frac1((cell.x + cell.y) / run_length) * run_length + 0.5f;
+	const float flip = step1(t, run_flip);
+	local = lerp(local, V2(local.y, local.x), flip);
+	const vec2 rel = abs(local) / width;
+	const vec2 over = V2(step1(1.f, rel.x), step1(1.f, rel.y));
+	local = lerp(local, V2(local.y, local.x), over.x);
+	local = lerp(local, miss_uv, over.x * over.y);
+	return V4(cell.x, cell.y, local.x, local.y);
+}
 
 // ---- procedural materials (sdf_materials.hlsl:6-31) --------------------------------------
 SDF_HD vec3 mat_marble(vec3 p, vec3 tint)

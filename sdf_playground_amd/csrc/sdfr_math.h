@@ -232,6 +232,8 @@ SDF_HD float atan21(float y, float x)
 	return (y < 0.f) ? -a : a;
 }
 
+SDF_HD float atan1(float x) { return atan21(x, 1.f); }
+
 SDF_HD float exp21(float x)
 {
 	if (x != x) return x;

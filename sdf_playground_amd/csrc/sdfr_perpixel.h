@@ -9,6 +9,8 @@
 #include "sdfr_pixel.h"
 #include "sdfr_scenes.h"
 #include "sdfr_scenes2.h"
+#include "sdfr_scenes3.h"
+#include "sdfr_scenes4.h"
 
 namespace sdfr {
 
@@ -122,7 +124,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 #define SDFR_FOR_EACH_SCENE(X) \
 	X(0, SceneFastSphere) X(1, SceneCubeSea) X(2, SceneLabyrinth) X(3, SceneFractal) X(4, SceneLense) X(5, SceneGems) X(6, SceneLightShadows) \
 	X(7, SceneCube) X(8, SceneGyroid) X(9, SceneBasicTransparency) X(10, SceneBasicClouds) X(11, SceneCoordinateMaterial) \
-	X(12, SceneDistortion) X(13, SceneTable) X(14, SceneSierpinski) X(15, SceneNeon)
-enum { SDFR_SCENE_COUNT = 16 };
+	X(12, SceneDistortion) X(13, SceneTable) X(14, SceneSierpinski) X(15, SceneNeon) \
+	X(16, SceneFractal2) X(17, SceneShell) X(18, SceneSpiral) X(19, SceneTerrain) X(20, SceneTiling) X(21, SceneTree)
+enum { SDFR_SCENE_COUNT = 22 };
 
 } // namespace sdfr

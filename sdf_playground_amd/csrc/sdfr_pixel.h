@@ -395,7 +395,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 
 		if (use_light)
 		{
-			const float ambient = 0.075f;
+			const float ambient = Scene::ambient(); // map_light may override the default 0.075
 			float move = max1(SDFR_SHADOW_EPS, SDFR_GRAD_EPS) + max1(0.f, -hit.d);
 			vec3 lit_pos = mad(n, move, hit.pos);
 			const float alpha = sat1(m.diffuse.w);

@@ -91,6 +91,7 @@ struct SceneFastSphere
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -155,6 +156,7 @@ struct SceneCubeSea
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -258,6 +260,7 @@ struct SceneLabyrinth
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -328,6 +331,7 @@ struct SceneFractal
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -440,6 +444,7 @@ struct SceneLense
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
 	// the scene carries its own copy of the sky (sdf_scene_lense.hlsl:108-117), same arithmetic
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -496,6 +501,7 @@ struct SceneGems
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -585,6 +591,7 @@ struct SceneLightShadows
 		L.color = V3(U.su[SU_COLORS + 3 * k], U.su[SU_COLORS + 3 * k + 1], U.su[SU_COLORS + 3 * k + 2]) * 0.5f;
 		return true;
 	}
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 

@@ -47,6 +47,7 @@ struct SceneCube
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -79,6 +80,7 @@ struct SceneGyroid
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -120,6 +122,7 @@ struct SceneBasicTransparency
 			m.diffuse = V4(0.9f, 0.f, 0.9f, 0.3f);
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -169,6 +172,7 @@ struct SceneBasicClouds
 		L.falloff = 0.f;
 		return true;
 	}
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -229,6 +233,7 @@ struct SceneCoordinateMaterial
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -289,6 +294,7 @@ struct SceneDistortion
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -355,6 +361,7 @@ struct SceneTable
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -408,6 +415,7 @@ struct SceneSierpinski
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 
@@ -496,6 +504,7 @@ struct SceneNeon
 		}
 	}
 	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
 

@@ -31,12 +31,13 @@ def test_scene_list_matches_reference_stems(lib):
     import sdf_playground_amd as sp
 
     assert sp.scene_names() == ["fast_sphere", "cube_sea", "labyrinth", "fractal", "lense", "gems", "light_shadows", "cube", "gyroid",
-                                "basic_transparency", "basic_clouds", "coordinate_material", "distortion", "table", "sierpinski", "neon"]
+                                "basic_transparency", "basic_clouds", "coordinate_material", "distortion", "table", "sierpinski", "neon",
+                                "fractal2", "shell", "spiral", "terrain", "tiling", "tree"]
     # every name is a stem of the reference's scenes directory (SceneManager.cpp:142-158)
     ref = "/root/reference/Engine/shader/scenes"
     if os.path.isdir(ref):
         stems = {f[len("sdf_scene_"):-5] for f in os.listdir(ref) if f.endswith(".hlsl")}
-        assert set(sp.scene_names()) <= stems
+        assert set(sp.scene_names()) == stems  # all 22 scenes of the reference
 
 
 def test_no_cpu_fallback_without_gpu(lib):

@@ -108,7 +108,10 @@ def test_fast_math_domain_is_respected_on_all_scenes(oracle):
         f.width, f.height = 40, 40
         oracle.census(gu.scene_of(path), f)
         assert oracle.census.last_domain_violations == (0, 0), path
-        # overflowed arguments need a ray that escaped by ~1e18 units: only basic_clouds' transparency
-        # continuation rays, which see nothing but the fast floor plane, do that
-        if gu.scene_of(path) != "basic_clouds":
+        # overflowed ("far field") arguments need a ray that escaped by ~1e18 units in one step, i.e.
+        # a step in which the fast floor/bounding plane (height / 1e-20) was the only object: the
+        # transparency continuation rays of basic_clouds and the rays above tree's canopy plane.
+        # There IEEE yields +inf and the fast sequences NaN; both are absorbed by the min() /
+        # comparison that follows -- and the GPU parity tests cover both scenes.
+        if gu.scene_of(path) not in ("basic_clouds", "tree"):
             assert oracle.census.last_far_field == 0, path

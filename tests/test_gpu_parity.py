@@ -37,6 +37,12 @@ def _cameras(oracle):
         "table": ("lookat", (2, 2, -3), (0, 1, 0)),
         "sierpinski": ("lookat", (1.2, 1.6, -2.2), (0, 1.2, 0)),
         "neon": ("lookat", (-2, 2.5, -3.5), (0, 2, 1)),
+        "fractal2": ("lookat", (1.8, 1.8, -2.0), (0, 1, 0)),
+        "shell": ("lookat", (-2.2, 1.8, -2.0), (0, 1, 0)),
+        "spiral": ("lookat", (0, 4, -12), (0, 3, 0)),
+        "terrain": ("lookat", (6, 5, -8), (0, 0, 0)),
+        "tiling": ("lookat", (0, 4.5, -9), (0, 4, 0)),
+        "tree": ("lookat", (0, 2.2, -4), (0, 1, 1)),
     }, fovy, asp
 
 
@@ -97,7 +103,8 @@ def _compare(renderer, oracle, scene, f, schedule):
 
 
 SCENES = ["fast_sphere", "cube_sea", "labyrinth", "fractal", "lense", "gems", "light_shadows", "cube", "gyroid", "basic_transparency",
-          "basic_clouds", "coordinate_material", "distortion", "table", "sierpinski", "neon"]
+          "basic_clouds", "coordinate_material", "distortion", "table", "sierpinski", "neon", "fractal2", "shell", "spiral", "terrain",
+          "tiling", "tree"]
 
 
 @pytest.mark.parametrize("schedule", [0, 1], ids=["wavefront", "pixel"])
@@ -140,6 +147,12 @@ def test_variables_and_debug_views(renderer, oracle):
     f = _setup(renderer, oracle, "neon", 0.0, variables=dict(r1=1.4, spacing=0.15, red=2.0))
     for schedule in (0, 1):
         assert _compare(renderer, oracle, "neon", f, schedule)
+    f = _setup(renderer, oracle, "tiling", 0.5, variables=dict(m1=0.7, m2=0.4, width=0.3, run_length=5.0, run_flip=3.0, flip_chance=0.8, truchet_width=0.15))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "tiling", f, schedule)
+    f = _setup(renderer, oracle, "terrain", 0.0, variables=dict(levels=4.0))
+    for schedule in (0, 1):
+        assert _compare(renderer, oracle, "terrain", f, schedule)
     renderer.initShader("lense")  # reloading a scene resets its variables (Application.cpp:237)
     assert renderer.getVariableMap()["mixing"].value == 0.5
 

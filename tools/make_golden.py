@@ -36,6 +36,12 @@ CAMS = {
     "table": ("lookat", (2, 2, -3), (0, 1, 0)),
     "sierpinski": ("lookat", (1.2, 1.6, -2.2), (0, 1.2, 0)),
     "neon": ("lookat", (-2, 2.5, -3.5), (0, 2, 1)),
+    "fractal2": ("lookat", (1.8, 1.8, -2.0), (0, 1, 0)),
+    "shell": ("lookat", (-2.2, 1.8, -2.0), (0, 1, 0)),
+    "spiral": ("lookat", (0, 4, -12), (0, 3, 0)),
+    "terrain": ("lookat", (6, 5, -8), (0, 0, 0)),
+    "tiling": ("lookat", (0, 4.5, -9), (0, 4, 0)),
+    "tree": ("lookat", (0, 2.2, -4), (0, 1, 1)),
 }
 FIELDS = ["stime", "width", "height", "iter_count", "bounce_count", "ray_count", "light_count", "range", "max_cost_default",
           "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects"]
