@@ -260,3 +260,19 @@ def test_kernels_reproduce_golden_fixtures(renderer):
             assert np.abs(img.astype(np.float64) - g["rgba"]).max() <= TOL
             assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32)), path
             assert np.array_equal(st, g["stats"].astype(np.uint32)), path
+
+
+def test_variable_tables_of_all_scenes(oracle):
+    """Names, order (std::map) and defaults of every scene's VAR_ table: C++ host parser of the
+    product vs the oracle's restatement (which the CPU tier checks against the reference's
+    scene files)."""
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    assert sp.scene_names() == oracle.scene_names()
+    for scene in sp.scene_names():
+        r.initShader(scene)
+        got = [(v.name, v.minval, v.maxval, v.start, v.step, v.value) for v in r.getVariableMap().values()]
+        want = [(row[0],) + tuple(float(np.float32(x)) for x in row[1:6]) for row in oracle.var_table(scene)]
+        assert got == want, scene
+    r.close()
