@@ -196,43 +196,82 @@ struct SceneLabyrinth
 		return d;
 	}
 
-	struct Objects { float wall, vase, wood, fire; vec3 torch_pos; };
-	static SDF_HD Objects eval_objects(vec3 p)
+	// 20 x 20 cells, mirrored into one octant
+	static SDF_HD vec3 fold(vec3 p)
 	{
-		Objects o;
-		// 20 x 20 cells, mirrored into one octant
 		vec2 rep = op_rep_inf_c(V2(p.x, p.z), 20.f, 1.0f / 20.f);
 		float wx = abs1(rep.x), wz = abs1(rep.y);
 		if (wz > wx) { float t = wx; wx = wz; wz = t; }
-		vec3 wp = V3(wx, p.y, wz);
-
+		return V3(wx, p.y, wz);
+	}
+	static SDF_HD float walls(vec3 wp)
+	{
 		float wall1 = sd_box(wp - V3(3.5f, 2.f, 3.f), V3(1.5f, 2.f, 1.f));
 		float wall2 = sd_box(wp - V3(7.f, 2.f, 5.f), V3(3.f, 2.f, 1.f));
-		o.wall = min1(wall1, wall2);
-
-		vec3 vp = wp;
-		vp.x = abs1(vp.x - 8.f);
-		o.vase = vase(vp - V3(1.f, 0.f, 3.f));
-
-		// torch: a tilted wooden stick with a flame cone
+		return min1(wall1, wall2);
+	}
+	// position in the vase's frame (the vase is mirrored about x = 8)
+	static SDF_HD vec3 vase_local(vec3 wp) { return V3(abs1(wp.x - 8.f), wp.y, wp.z) - V3(1.f, 0.f, 3.f); }
+	// torch: a tilted wooden stick with a flame cone
+	struct Torch { float wood, fire; vec3 torch_pos; };
+	static SDF_HD Torch torch(vec3 wp)
+	{
+		Torch t;
 		const float torch_angle = 15.f * SDFR_PI / 180.f;
 		const float tc = cos1(torch_angle), ts = sin1(torch_angle);
 		vec3 tp = wp - V3(5.f, 2.f, 3.f);
 		vec3 sp = V3(tp.x * tc - tp.y * ts, tp.x * ts + tp.y * tc, tp.z);
 		tp.x = tp.x - 0.3f;
-		o.wood = sd_box(sp - V3(0.f, 0.6f, 0.f), V3(0.05f, 0.5f, 0.05f));
-		o.fire = fire_cone(tp);
-		o.torch_pos = tp;
+		t.wood = sd_box(sp - V3(0.f, 0.6f, 0.f), V3(0.05f, 0.5f, 0.05f));
+		t.fire = fire_cone(tp);
+		t.torch_pos = tp;
+		return t;
+	}
+
+	struct Objects { float wall, vase, wood, fire; vec3 torch_pos; };
+	static SDF_HD Objects eval_objects(vec3 p)
+	{
+		Objects o;
+		const vec3 wp = fold(p);
+		o.wall = walls(wp);
+		o.vase = vase(vase_local(wp));
+		const Torch t = torch(wp);
+		o.wood = t.wood;
+		o.fire = t.fire;
+		o.torch_pos = t.torch_pos;
 		return o;
+	}
+
+	// Bounding-ball culling of the two small, expensive objects.  The scene distance is a
+	// min() over objects, so an object whose distance is provably >= the running minimum can
+	// be left out without changing a single bit.  Bounds (checked numerically by
+	// tests/test_scene_bounds_cpu.py):
+	//   vase: every part lies in the ball (0, 1.2, 0), r 1.35 of its frame; sphere, capped
+	//         cylinder and box are exact SDFs, so each is >= |q - c| - 1.35; the two pipe merges
+	//         lower the result by at most 0.075 each (op_pipe(a, b) >= min(a, b) - 0.075 for
+	//         min(a, b) >= 0.05 with size 0.1, count 4); the final max() only raise it;
+	//   torch: stick and flame (exact SDFs) lie in the ball (0.2, 0.9, 0), r 0.9 of the torch frame.
+	// 0.01 of slack covers fp32 rounding (the quantities are O(1)).
+	static SDF_HD bool beyond(vec3 v, float reach, float radius)
+	{
+		const float k = reach + radius;
+		return dot(v, v) >= k * k;
 	}
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		Objects o = eval_objects(p);
-		d = min1(d, o.wall);
-		d = min1(d, o.vase);
-		d = min1(d, o.wood);
-		return R.skip_fire ? d : min1(d, o.fire);
+		const vec3 wp = fold(p);
+		d = min1(d, walls(wp));
+		const vec3 q = vase_local(wp);
+		if (!beyond(q - V3(0.f, 1.2f, 0.f), max1(d, 0.f), 1.35f + 0.15f + 0.01f))
+			d = min1(d, vase(q));
+		if (!beyond(wp - V3(5.f, 2.f, 3.f) - V3(0.2f, 0.9f, 0.f), max1(d, 0.f), 0.9f + 0.01f))
+		{
+			const Torch t = torch(wp);
+			d = min1(d, t.wood);
+			d = R.skip_fire ? d : min1(d, t.fire);
+		}
+		return d;
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

@@ -79,3 +79,31 @@ extern "C" float hostsim_math(int fn, float a, float b)
 	default: return 0.f;
 	}
 }
+
+// Numerical check of the bounding-ball lower bounds the labyrinth functor culls with
+// (sdfr_scenes.h): returns the number of sampled points that violate a bound.
+extern "C" long long hostsim_check_labyrinth_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 12345ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		// vase frame
+		const vec3 q = V3(rnd() * 12.f - 6.f, rnd() * 10.f - 3.f, rnd() * 12.f - 6.f);
+		const float lb = length(q - V3(0.f, 1.2f, 0.f)) - 1.35f - 0.15f;
+		if (lb >= 0.f && SceneLabyrinth::vase(q) < lb - 1e-4f) ++bad;
+		// torch frame (wp - (5, 2, 3))
+		const vec3 t0 = V3(rnd() * 8.f - 4.f, rnd() * 8.f - 3.f, rnd() * 8.f - 4.f);
+		const SceneLabyrinth::Torch t = SceneLabyrinth::torch(t0 + V3(5.f, 2.f, 3.f));
+		const float lbt = length(t0 - V3(0.2f, 0.9f, 0.f)) - 0.9f;
+		if (lbt >= 0.f && (t.wood < lbt - 1e-4f || t.fire < lbt - 1e-4f)) ++bad;
+		// pipe merge bound
+		const float a = rnd() * 3.f + 0.05f, b = rnd() * 3.f + 0.05f;
+		if (op_pipe(a, b, 0.1f, 4.f) < min1(a, b) - 0.075f - 1e-5f) ++bad;
+	}
+	return bad;
+}

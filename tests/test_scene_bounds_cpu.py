@@ -1,0 +1,33 @@
+"""CPU tier: the lower bounds the labyrinth functor uses to cull its vase and torch
+(sdf_playground_amd/csrc/sdfr_scenes.h, SceneLabyrinth::dist) hold on dense random samples,
+and culling leaves every pixel bit-identical to the oracle from cameras close to those
+objects."""
+import ctypes
+import math
+
+import numpy as np
+
+
+def test_labyrinth_bounds_hold_on_random_samples():
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_labyrinth_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_labyrinth_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_labyrinth_bounds(3000000, 7) == 0
+
+
+def test_culling_is_invisible_near_vases_and_torches(oracle):
+    import hostsim
+
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    views = [((6.2, 1.6, 1.4), (7.0, 1.0, 3.0)), ((9.6, 2.4, 1.2), (9.0, 1.2, 3.0)), ((5.4, 3.2, 1.2), (5.2, 3.0, 3.0)),
+             ((3.0, 0.8, 0.5), (9.0, 1.5, 3.0)), ((7.5, 6.0, 7.5), (7.5, 0.0, 3.0)), ((-12.8, 2.5, -17.2), (-11.0, 2.0, -17.0))]
+    for eye, at in views:
+        for stime in (0.0, 0.9):
+            f = oracle.default_frame("labyrinth", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=stime)
+            f.iter_count = 256
+            ref, rst, _ = oracle.render("labyrinth", f, stats=True)
+            img, st = hostsim.render("labyrinth", hostsim.frame_from_oracle(f))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+            assert np.array_equal(st, rst)
