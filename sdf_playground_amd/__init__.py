@@ -20,7 +20,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfr.so")
+LIB_PATH = os.environ.get("SDFR_LIBRARY") or os.path.join(_HERE, "libsdfr.so")  # SDFR_LIBRARY: developer builds (tools/phase_clocks.py)
 
 SDFR_OK = 0
 SCHEDULE_WAVEFRONT = 0

@@ -24,18 +24,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    """Compile every HIP source for gfx950 into sdf_playground_amd/libsdfr.so."""
-    if not force and not _stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """Compile every HIP source for gfx950 into sdf_playground_amd/libsdfr.so (or `out`)."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-x", "hip",
            "-Wno-unused-result", "-Wno-unknown-pragmas", "-I" + CSRC] + list(extra)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

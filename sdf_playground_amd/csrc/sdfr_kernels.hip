@@ -179,7 +179,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint3
 	RenderTotals *totals, float *ray_queue, size_t cap)
 {
 	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
-	PixelCounters c = {0, 0, 0};
+	PixelCounters c = {};
 	uint32_t npix = 0;
 	PixelCoord pc;
 	if (w < n_work && work_to_pixel(U, rm, w, pc))
@@ -196,6 +196,19 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint3
 		}
 		npix = 1;
 	}
+#ifdef SDFR_PHASE_CLOCKS
+	// the totals carry wave clocks instead of counts: pixels <- whole pixel loop, rays <- march,
+	// march_evals <- normals, hits <- shading; per wave the lane that stayed longest speaks
+	{
+		uint64_t best = c.clk_total;
+		for (int off = 32; off > 0; off >>= 1) { uint64_t o = __shfl_xor(best, off); best = o > best ? o : best; }
+		const uint64_t first = __ballot(c.clk_total == best);
+		const bool speaker = (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(first);
+		block_add_totals(totals, speaker ? (uint32_t)(c.clk_total >> 4) : 0u, speaker ? (uint32_t)(c.clk_march >> 4) : 0u,
+			speaker ? (uint32_t)(c.clk_grad >> 4) : 0u, speaker ? (uint32_t)(c.clk_shade >> 4) : 0u);
+		return;
+	}
+#endif
 	block_add_totals(totals, npix, c.rays, c.march_evals, c.hits);
 }
 

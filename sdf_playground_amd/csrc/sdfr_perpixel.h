@@ -49,7 +49,21 @@ struct CachedRayStore
 	}
 };
 
-struct PixelCounters { uint32_t rays, march_evals, hits; };
+struct PixelCounters
+{
+	uint32_t rays, march_evals, hits;
+#ifdef SDFR_PHASE_CLOCKS
+	// developer build (tools/phase_clocks.py): wave clock spent marching / taking normals / shading
+	uint64_t clk_march, clk_grad, clk_shade, clk_total;
+#endif
+};
+#ifdef SDFR_PHASE_CLOCKS
+#define SDFR_CLK(var) const uint64_t var = __builtin_readcyclecounter()
+#define SDFR_CLK_ADD(field, t0, t1) cnt.field += (t1) - (t0)
+#else
+#define SDFR_CLK(var)
+#define SDFR_CLK_ADD(field, t0, t1)
+#endif
 
 // `store` holds the pixel's pending rays (put/get by slot).  The primary ray never enters
 // it: the reference pops it from slot 0 before anything is pushed (pshader_sdf.hlsl:289-294),
@@ -57,6 +71,7 @@ struct PixelCounters { uint32_t rays, march_evals, hits; };
 template <class Scene, bool DBG, class Store>
 SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, Store &store)
 {
+	SDFR_CLK(c_begin);
 	const DebugFlags F = debug_flags(U);
 	const PixelRay pr = pixel_ray(U, px, py);
 	RayRec ray = primary_ray(U, pr);
@@ -81,6 +96,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		const float inside_sign = ray_inside_sign(ray);
 		const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
 
+		SDFR_CLK(c0);
 		March m = march_begin(ray.pos, ray.dir);
 		int status;
 		do
@@ -90,6 +106,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			cnt.march_evals++;
 			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
 		} while (status == MARCH_CONTINUE);
+		SDFR_CLK(c1);
+		SDFR_CLK_ADD(clk_march, c0, c1);
 
 		vec3 out;
 		if (status == MARCH_HIT)
@@ -105,11 +123,21 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
 			float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
 			hit.normal = normalize(V3(g0, g1, g2));
+#ifdef SDFR_PHASE_CLOCKS
+			asm volatile("" : "+v"(hit.normal.x), "+v"(hit.normal.y), "+v"(hit.normal.z));
+#endif
+			SDFR_CLK(c2);
+			SDFR_CLK_ADD(clk_grad, c1, c2);
 
 			Spawner<Store> q(store, depths, count, U.ray_count);
 			out = shade_hit<Scene, DBG, Store>(U, F, ray, pr, hit, max_range, hdr, q);
 			depths = q.depths;
 			count = q.count;
+#ifdef SDFR_PHASE_CLOCKS
+			asm volatile("" : "+v"(out.x), "+v"(out.y), "+v"(out.z));
+#endif
+			SDFR_CLK(c3);
+			SDFR_CLK_ADD(clk_shade, c2, c3);
 		}
 		else
 		{
@@ -117,6 +145,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		}
 		acc = acc + out;
 	}
+	SDFR_CLK(c_end);
+	SDFR_CLK_ADD(clk_total, c_begin, c_end);
 	return V4(acc.x, acc.y, acc.z, abs1(hdr));
 }
 

@@ -151,20 +151,20 @@ SDF_HD vec3 march_pos(const March &m) { return mad(m.dir, m.t, m.start); }
 // consume one scene-distance sample `d` taken at march_pos(m); requires m.iter < iter_count
 SDF_HD int march_advance(March &m, float d, float dist_max, uint32_t iter_count)
 {
+	// written with selects instead of branches: the loop body is short and every lane of the wave
+	// takes one of the three ways each iteration
 	m.d = d;
-	if (m.factor > 1.f && (m.last_d + d) < m.last_d * m.factor)
-	{
-		// over-stepped: rewind to the last safe point and continue without relaxation
-		m.t = m.last_safe;
-		m.factor = 1.f;
-		m.iter++;
-		return m.iter < iter_count ? MARCH_CONTINUE : MARCH_MISS;
-	}
-	m.last_d = d;
-	if (m.t > dist_max) return MARCH_MISS;
-	if (d < SDFR_DIST_EPS) return MARCH_HIT;
-	m.last_safe = m.t + d;
-	m.t = m.t + d * m.factor;
+	// over-stepped: rewind to the last safe point and continue without relaxation
+	const bool over = (m.factor > 1.f) & ((m.last_d + d) < m.last_d * m.factor);
+	const bool out_of_range = m.t > dist_max;
+	const bool stop = !over & (out_of_range | (d < SDFR_DIST_EPS));
+	const float t_fwd = m.t + d * m.factor;
+	const float safe_fwd = m.t + d;
+	m.last_d = over ? m.last_d : d;
+	m.t = stop ? m.t : (over ? m.last_safe : t_fwd);
+	m.last_safe = (over | stop) ? m.last_safe : safe_fwd;
+	m.factor = over ? 1.f : m.factor;
+	if (stop) return out_of_range ? MARCH_MISS : MARCH_HIT;
 	m.iter++;
 	return m.iter < iter_count ? MARCH_CONTINUE : MARCH_MISS;
 }
