@@ -17,6 +17,7 @@
 #ifndef SDFR_H
 #define SDFR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -33,7 +34,8 @@ typedef enum sdfr_status
 	SDFR_ERR_UNKNOWN_VARIABLE = -3, /* value ignored, like ShaderVariableManager::setValue (ShaderUtil.cpp:234-240) */
 	SDFR_ERR_NO_SCENE = -4,         /* render without a loaded scene: SDFRenderer::render returns false (SDFRenderer.cpp:70-73) */
 	SDFR_ERR_HIP = -5,
-	SDFR_ERR_NO_DEVICE = -6
+	SDFR_ERR_NO_DEVICE = -6,
+	SDFR_ERR_COMPILE = -7 /* a run-time scene does not compile: sdfr_last_error holds the compiler's messages */
 } sdfr_status;
 
 /* ---- lifetime: SDFRenderer::init(Graphics&) (SDFRenderer.cpp:9-25) ----------------------- */
@@ -50,6 +52,19 @@ int sdfr_scene_count(void);
 const char *sdfr_scene_name(int index);
 int sdfr_load_scene(sdfr_renderer *r, const char *name);
 const char *sdfr_current_scene(const sdfr_renderer *r);
+/* Compile a scene from source text at run time -- the reference's edit-and-reload workflow
+ * (SceneManager.cpp:102-133 re-runs SDFRenderer::initShader -> D3DCompile when a scene file
+ * changes).  `source` is HIP C++ defining `struct Scene` with the scene interface of
+ * sdf_playground_amd/scenes/README.md (the reference's map / map_light / map_background split
+ * into dist / material / light / background); VAR_<name>(min = .., max = .., ..) tags in the text
+ * declare variables exactly as in the reference's .hlsl scenes (ShaderUtil.cpp:122-191).  On
+ * SDFR_ERR_COMPILE the previously loaded scene stays active, as in the reference
+ * (SceneManager.cpp:118-127).  Needs libhiprtc.so and the kernel headers (csrc/ beside the
+ * library, or $SDFR_JIT_INCLUDE). */
+int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *source);
+/* Same compilation without a device or a handle (build machines, editors): SDFR_OK, or
+ * SDFR_ERR_COMPILE / SDFR_ERR_INVALID_ARGUMENT with the messages in `log`.  arch: "gfx950" (NULL = that). */
+int sdfr_check_scene_source(const char *source, const char *arch, char *log, size_t log_bytes);
 
 /* ---- parameter surface 1: shader variables = SDFRenderer::getVariableMap()
  *      (ShaderVariable.h:6-12; ShaderUtil.cpp:122-267).  Index order = std::map order

@@ -70,15 +70,16 @@ public:
 	bool initShader(const std::string &scene)
 	{
 		if (sdfr_load_scene(handle, scene.c_str()) != SDFR_OK) return false;
-		variables.clear();
-		const int n = sdfr_var_count(handle);
-		for (int i = 0; i < n; ++i)
-		{
-			sdfr_variable v;
-			if (sdfr_var_info(handle, i, &v) != SDFR_OK) return false;
-			variables[v.name] = Variable{v.minval, v.maxval, v.start, v.step, v.value};
-		}
-		return true;
+		return refreshVariables();
+	}
+
+	// the same with the scene given as source text, compiled at run time (the reference re-runs
+	// initShader when a scene file changes, SceneManager.cpp:102-133); false = does not compile,
+	// lastError() has the compiler's messages and the previous scene stays active
+	bool initShaderSource(const std::string &name, const std::string &source)
+	{
+		if (sdfr_load_scene_source(handle, name.c_str(), source.c_str()) != SDFR_OK) return false;
+		return refreshVariables();
 	}
 
 	// void setParameters(float stime)
@@ -107,6 +108,19 @@ public:
 	sdfr_renderer *native() { return handle; }
 
 private:
+	bool refreshVariables()
+	{
+		variables.clear();
+		const int n = sdfr_var_count(handle);
+		for (int i = 0; i < n; ++i)
+		{
+			sdfr_variable v;
+			if (sdfr_var_info(handle, i, &v) != SDFR_OK) return false;
+			variables[v.name] = Variable{v.minval, v.maxval, v.start, v.step, v.value};
+		}
+		return true;
+	}
+
 	sdfr_renderer *handle = nullptr;
 	VariableMap variables;
 	float stime = 0.f;

@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source",
 ]
 
 _lib = None
@@ -102,6 +102,8 @@ def load_library():
     L.sdfr_scene_name.argtypes = [ci]
     L.sdfr_scene_name.restype = ctypes.c_char_p
     L.sdfr_load_scene.argtypes = [vp, ctypes.c_char_p]
+    L.sdfr_load_scene_source.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.sdfr_check_scene_source.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.sdfr_current_scene.argtypes = [vp]
     L.sdfr_current_scene.restype = ctypes.c_char_p
     L.sdfr_var_count.argtypes = [vp]
@@ -135,6 +137,16 @@ def load_library():
 def scene_names():
     L = load_library()
     return [L.sdfr_scene_name(i).decode() for i in range(L.sdfr_scene_count())]
+
+
+def check_scene_source(source, arch="gfx950"):
+    """Compile a run-time scene without a device; returns (ok, compiler messages)."""
+    if os.path.exists(source):
+        with open(source) as f:
+            source = f.read()
+    log = ctypes.create_string_buffer(1 << 16)
+    rc = load_library().sdfr_check_scene_source(source.encode(), arch.encode(), log, len(log))
+    return rc == SDFR_OK, log.value.decode(errors="replace")
 
 
 def strip_buffer_pixels(width, height, world):
@@ -247,6 +259,16 @@ class SDFRenderer:
         return True
 
     loadScene = initShader
+
+    # the reference's edit-and-reload: compile a scene from its source text (hiprtc).  `source`
+    # is the text or a path to it; on a compile error the previous scene stays active and
+    # SdfrError carries the compiler's messages (SceneManager.cpp:118-127)
+    def initShaderSource(self, name, source):
+        if os.path.exists(source):
+            with open(source) as f:
+                source = f.read()
+        self._check(self._L.sdfr_load_scene_source(self._h, name.encode(), source.encode()))
+        return True
 
     def currentScene(self):
         s = self._L.sdfr_current_scene(self._h)

@@ -6,6 +6,8 @@
     python -m sdf_playground_amd.cli --scene lense --set mixing=0.8 --set zpos=9 --time 1.5 \\
             --size 1200x800 --eye 0,0.5,7 --lookat 0,0,0 --out lense.png
     python -m sdf_playground_amd.cli --parse-hlsl path/to/sdf_scene_x.hlsl      # VAR_ tags of a scene file
+    python -m sdf_playground_amd.cli --scene-source sdf_playground_amd/scenes/pendulum.scene.h --out p.png
+    python -m sdf_playground_amd.cli --scene-source my.scene.h --check              # compile only, no GPU
 
 --out writes the tone-mapped + bloomed LDR image (HDR::process, like the reference's window);
 --out-hdr writes the raw float32 RGBA frame as .npy.  Needs a GPU.
@@ -71,6 +73,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="sdf_playground_amd.cli", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--list-scenes", action="store_true")
     ap.add_argument("--scene")
+    ap.add_argument("--scene-source", metavar="FILE", help="scene compiled at run time (scenes/README.md)")
+    ap.add_argument("--check", action="store_true", help="with --scene-source: compile only, no GPU needed")
     ap.add_argument("--list-vars", action="store_true")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--time", type=float, default=0.0)
@@ -98,10 +102,24 @@ def main(argv=None):
     if a.list_scenes:
         print("\n".join(sp.scene_names()))
         return 0
-    if not a.scene:
-        ap.error("--scene is required")
+    if a.scene_source and a.check:
+        ok, log = sp.check_scene_source(a.scene_source)
+        print("ok" if ok else log)
+        return 0 if ok else 1
+    if not a.scene and not a.scene_source:
+        ap.error("--scene or --scene-source is required")
     r = sp.SDFRenderer(a.device)
-    r.initShader(a.scene)
+    if a.scene_source:
+        import os
+
+        a.scene = os.path.basename(a.scene_source).split(".")[0]
+        try:
+            r.initShaderSource(a.scene, a.scene_source)
+        except sp.SdfrError as e:
+            print(e, file=sys.stderr)
+            return 1
+    else:
+        r.initShader(a.scene)
     for item in a.set:
         name, _, value = item.partition("=")
         if not r.setValue(name, float(value)):

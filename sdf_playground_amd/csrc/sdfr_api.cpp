@@ -7,11 +7,13 @@
 
 #include "sdfr_hostframe.h"
 #include "sdfr_hostlib.h"
+#include "sdfr_jit.h"
 #include "sdfr_kernels.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -28,7 +30,8 @@ struct sdfr_renderer
 {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	int scene = -1;
+	int scene = -1; // index of an ahead-of-time scene, or SDFR_SCENE_COUNT: `jit` holds a scene compiled at run time
+	JitScene jit;
 	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
 	bool profiling = false;
 	int tile_w_log2 = 3;
@@ -151,6 +154,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	hipSetDevice(r->device);
 	hipStreamSynchronize(r->stream);
 	free_workspace(r);
+	jit_unload(r->jit);
 	hipFree(r->d_totals);
 	hipFree(r->d_stage);
 	hipFree(r->d_pstat);
@@ -176,40 +180,94 @@ int sdfr_set_stream(sdfr_renderer *r, void *hip_stream)
 int sdfr_scene_count(void) { return SDFR_SCENE_COUNT; }
 const char *sdfr_scene_name(int index) { return scene_name(index); }
 
+// rebuild the variable table like SDFRenderer::initShader (SDFRenderer.cpp:35-47): clear, then
+// collect the tags of the driver and of the scene text
+static int build_variable_table(sdfr_renderer *r, const std::string &scene_text, host::ShaderVariableManager &vm, std::vector<std::string> &slots)
+{
+	// scene slots: distinct names of the scene's tags in order of appearance
+	std::vector<std::string_view> code, tags;
+	host::split_tagged(scene_text, "VAR_", ")", code, tags);
+	for (std::string_view t : tags)
+	{
+		const size_t lb = t.find('(');
+		if (lb == std::string_view::npos || lb <= 4) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag: '" + std::string(t) + "'");
+		std::string nm(t.substr(4, lb - 4));
+		for (char c : nm)
+			if (!isalnum((unsigned char)c) && c != '_') return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag: '" + std::string(t) + "'");
+		bool seen = false;
+		for (const auto &s : slots) seen = seen || s == nm;
+		if (!seen) slots.push_back(nm);
+	}
+	if (slots.size() > SDFR_MAX_SCENE_VARS) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "too many scene variables");
+	try
+	{
+		if (!vm.parseFile(std::string(k_driver_variables) + " " + scene_text)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag");
+	}
+	catch (const std::exception &) // a value that is not a number
+	{
+		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag: value is not a number");
+	}
+	return SDFR_OK;
+}
+
 int sdfr_load_scene(sdfr_renderer *r, const char *name)
 {
 	if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
 	const int idx = scene_index(name);
 	if (idx < 0) return fail(r, SDFR_ERR_UNKNOWN_SCENE, std::string("unknown scene '") + name + "'");
-	// rebuild the variable table like SDFRenderer::initShader: clear, then collect the tags of
-	// the driver and of the scene
 	host::ShaderVariableManager vm;
-	const std::string scene_tags = scene_variables(idx);
-	if (!vm.parseFile(std::string(k_driver_variables) + " " + scene_tags))
-		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "malformed VAR_ tag");
-	// scene slots: distinct names of the scene's tags in order of appearance
-	host::ShaderVariableManager scene_only;
-	scene_only.parseFile(scene_tags);
 	std::vector<std::string> slots;
-	{
-		std::vector<std::string_view> code, tags;
-		host::split_tagged(scene_tags, "VAR_", ")", code, tags);
-		for (std::string_view t : tags)
-		{
-			std::string nm(t.substr(4, t.find('(') - 4));
-			bool seen = false;
-			for (const auto &s : slots) seen = seen || s == nm;
-			if (!seen) slots.push_back(nm);
-		}
-	}
-	if (slots.size() > SDFR_MAX_SCENE_VARS) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "too many scene variables");
+	const int rc = build_variable_table(r, scene_variables(idx), vm, slots);
+	if (rc != SDFR_OK) return rc;
 	r->vars = vm;
 	r->scene_var_slots = slots;
 	r->scene = idx;
 	return SDFR_OK;
 }
 
-const char *sdfr_current_scene(const sdfr_renderer *r) { return (r && r->scene >= 0) ? scene_name(r->scene) : nullptr; }
+int sdfr_check_scene_source(const char *source, const char *arch, char *log, size_t log_bytes)
+{
+	if (!source) return SDFR_ERR_INVALID_ARGUMENT;
+	if (log && log_bytes) log[0] = 0;
+	sdfr_renderer scratch; // only its error string is used
+	host::ShaderVariableManager vm;
+	std::vector<std::string> slots;
+	std::string err;
+	int rc = build_variable_table(&scratch, source, vm, slots);
+	if (rc != SDFR_OK) err = scratch.error;
+	std::vector<char> code;
+	if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", source, slots, code, err)) rc = SDFR_ERR_COMPILE;
+	if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
+	return rc;
+}
+
+int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *source)
+{
+	if (!r || !name || !source) return SDFR_ERR_INVALID_ARGUMENT;
+	SDFR_HIP(hipSetDevice(r->device));
+	host::ShaderVariableManager vm;
+	std::vector<std::string> slots;
+	const int rc = build_variable_table(r, source, vm, slots);
+	if (rc != SDFR_OK) return rc;
+	JitScene js;
+	std::string err;
+	// like the reference, a scene that fails to compile leaves the previous one in place
+	// (SceneManager.cpp:118-127 keeps the old shader and shows the compiler's message)
+	if (!jit_compile(r->device, name, source, slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
+	SDFR_HIP(hipStreamSynchronize(r->stream));
+	jit_unload(r->jit);
+	r->jit = js;
+	r->vars = vm;
+	r->scene_var_slots = slots;
+	r->scene = SDFR_SCENE_COUNT;
+	return SDFR_OK;
+}
+
+const char *sdfr_current_scene(const sdfr_renderer *r)
+{
+	if (!r || r->scene < 0) return nullptr;
+	return r->scene == SDFR_SCENE_COUNT ? r->jit.name.c_str() : scene_name(r->scene);
+}
 
 int sdfr_var_count(const sdfr_renderer *r) { return r ? (int)r->vars.getVariables().size() : SDFR_ERR_INVALID_ARGUMENT; }
 
@@ -390,6 +448,7 @@ static int latch_frame(sdfr_renderer *r, int width, int height)
 	for (int i = 0; i < SDFR_MAX_SCENE_VARS; ++i) U.scene_var[i] = 0.f;
 	for (size_t k = 0; k < r->scene_var_slots.size(); ++k) U.scene_var[k] = val(r->scene_var_slots[k].c_str());
 	frame_derive(U, r->scene);
+	if (r->scene == SDFR_SCENE_COUNT) SDFR_HIP(jit_prepare(r->jit, U, r->stream));
 	return SDFR_OK;
 }
 
@@ -445,7 +504,12 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm));
 	if (rc != SDFR_OK) return rc;
 	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
-	if (r->schedule == SDFR_SCHEDULE_PIXEL)
+	if (r->scene == SDFR_SCENE_COUNT) // scenes compiled at run time exist for the PIXEL schedule only
+	{
+		e = jit_launch_pixel(r->jit, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream);
+		r->last_wavefront = false;
+	}
+	else if (r->schedule == SDFR_SCHEDULE_PIXEL)
 	{
 		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream);
 		r->last_wavefront = false;

@@ -84,4 +84,22 @@ struct Light
 	float falloff;
 };
 
+// device-side totals of one render
+struct RenderTotals
+{
+	unsigned long long pixels, rays, march_evals, hits;
+};
+
+// Which rows of the full frame this launch renders: local row l is global row
+// ((l / 8) * world + rank) * 8 + l % 8 (8-row strips dealt round-robin over ranks).
+// world = 1, rank = 0 is the whole frame.
+struct RowMap
+{
+	int local_rows;
+	int rank, world;
+	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
+};
+
+enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1 };
+
 } // namespace sdfr

@@ -1,0 +1,205 @@
+// sdfr_jit.cpp -- scenes compiled at run time.
+//
+// The reference builds a scene INTO its pixel shader when the scene is selected and again
+// whenever its file changes (SceneManager.cpp:102-133, SDFRenderer::initShader
+// SDFRenderer.cpp:27-53 with D3DCompile).  The equivalent here: the text of a scene functor
+// (the same shape as the ahead-of-time scenes of sdfr_scenes*.h, named `Scene`) is wrapped
+// into a translation unit around sdfr_pixel_kernel.h, compiled for the device's architecture
+// with hiprtc and loaded as a module.  The pixel kernel body is the one the ahead-of-time
+// scenes use, so a scene renders the same bits either way.
+//
+// VAR_ tags: as in the reference (ShaderUtil.cpp:122-191) the variable table is discovered by
+// scanning the source text for `VAR_<name>(key = value, ...)`.  Inside a method that receives
+// the frame uniforms as `U`, the tag itself is an expression: the generated prelude defines
+// `VAR_<name>(...)` as `(U.scene_var[k])`, k = order of first appearance.
+//
+// libhiprtc.so is opened on first use: the library has no load-time dependency on it.
+#include "sdfr_jit.h"
+#include "sdfr_pixel.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace sdfr {
+
+namespace {
+
+struct Hiprtc
+{
+	void *lib = nullptr;
+	decltype(&hiprtcCreateProgram) create = nullptr;
+	decltype(&hiprtcCompileProgram) compile = nullptr;
+	decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+	decltype(&hiprtcGetProgramLog) log = nullptr;
+	decltype(&hiprtcGetCodeSize) code_size = nullptr;
+	decltype(&hiprtcGetCode) code = nullptr;
+	decltype(&hiprtcDestroyProgram) destroy = nullptr;
+	decltype(&hiprtcGetErrorString) error_string = nullptr;
+	bool ok = false;
+};
+
+Hiprtc &hiprtc()
+{
+	static Hiprtc h;
+	if (h.lib) return h;
+	const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+	for (const char *n : names)
+		if ((h.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+	if (!h.lib) return h;
+	h.create = (decltype(h.create))dlsym(h.lib, "hiprtcCreateProgram");
+	h.compile = (decltype(h.compile))dlsym(h.lib, "hiprtcCompileProgram");
+	h.log_size = (decltype(h.log_size))dlsym(h.lib, "hiprtcGetProgramLogSize");
+	h.log = (decltype(h.log))dlsym(h.lib, "hiprtcGetProgramLog");
+	h.code_size = (decltype(h.code_size))dlsym(h.lib, "hiprtcGetCodeSize");
+	h.code = (decltype(h.code))dlsym(h.lib, "hiprtcGetCode");
+	h.destroy = (decltype(h.destroy))dlsym(h.lib, "hiprtcDestroyProgram");
+	h.error_string = (decltype(h.error_string))dlsym(h.lib, "hiprtcGetErrorString");
+	h.ok = h.create && h.compile && h.log_size && h.log && h.code_size && h.code && h.destroy && h.error_string;
+	return h;
+}
+
+// directory of the kernel headers: $SDFR_JIT_INCLUDE, or csrc/ beside the loaded library
+std::string header_dir()
+{
+	if (const char *e = getenv("SDFR_JIT_INCLUDE")) return e;
+	Dl_info info;
+	if (dladdr((const void *)&header_dir, &info) && info.dli_fname)
+	{
+		std::string p = info.dli_fname;
+		const size_t slash = p.rfind('/');
+		return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/csrc";
+	}
+	return "csrc";
+}
+
+} // namespace
+
+std::string jit_translation_unit(const std::string &scene_source, const std::vector<std::string> &var_slots)
+{
+	std::string tu;
+	tu += "#include \"sdfr_pixel_kernel.h\"\n";
+	tu += "namespace sdfr {\n";
+	for (size_t k = 0; k < var_slots.size(); ++k)
+		tu += "#define VAR_" + var_slots[k] + "(...) (U.scene_var[" + std::to_string(k) + "])\n";
+	tu += "#line 1 \"scene\"\n";
+	tu += scene_source;
+	tu += "\n#line 1 \"sdfr_jit_kernels\"\n";
+	tu += "extern \"C\" __global__ void sdfr_jit_prepare(FrameU *U) { if (blockIdx.x == 0 && threadIdx.x == 0) Scene::prepare(*U); }\n";
+	tu += "extern \"C\" __global__ __launch_bounds__(SDFR_BLOCK) void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
+		  "\tuint32_t *pixel_stats, RenderTotals *totals, float *ray_queue, size_t cap)\n"
+		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, totals, ray_queue, cap); }\n";
+	tu += "extern \"C\" __global__ __launch_bounds__(SDFR_BLOCK) void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
+		  "\tuint32_t *pixel_stats, RenderTotals *totals, float *ray_queue, size_t cap)\n"
+		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, totals, ray_queue, cap); }\n";
+	tu += "} // namespace sdfr\n";
+	return tu;
+}
+
+void jit_unload(JitScene &js)
+{
+	if (js.module) (void)hipModuleUnload(js.module);
+	if (js.d_frame) (void)hipFree(js.d_frame);
+	js = JitScene();
+}
+
+bool jit_compile_code(const std::string &arch_name, const std::string &name, const std::string &scene_source, const std::vector<std::string> &var_slots,
+	std::vector<char> &code, std::string &error)
+{
+	Hiprtc &rtc = hiprtc();
+	if (!rtc.ok)
+	{
+		error = "run-time scene compilation needs libhiprtc.so, which could not be loaded";
+		return false;
+	}
+	const std::string tu = jit_translation_unit(scene_source, var_slots);
+	hiprtcProgram prog = nullptr;
+	hiprtcResult rc = rtc.create(&prog, tu.c_str(), (name + ".scene.hip").c_str(), 0, nullptr, nullptr);
+	if (rc != HIPRTC_SUCCESS)
+	{
+		error = std::string("hiprtcCreateProgram: ") + rtc.error_string(rc);
+		return false;
+	}
+	// same code generation rules as the ahead-of-time build (buildlib.py): only explicit fma() fuses
+	const std::string arch = "--offload-arch=" + arch_name;
+	const std::string inc = "-I" + header_dir();
+	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", inc.c_str()};
+	rc = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+	size_t log_bytes = 0;
+	rtc.log_size(prog, &log_bytes);
+	std::string log(log_bytes, '\0');
+	if (log_bytes > 1) rtc.log(prog, log.data());
+	if (rc != HIPRTC_SUCCESS)
+	{
+		error = "scene '" + name + "' does not compile (" + rtc.error_string(rc) + "):\n" + log.c_str();
+		rtc.destroy(&prog);
+		return false;
+	}
+	size_t code_bytes = 0;
+	rtc.code_size(prog, &code_bytes);
+	code.resize(code_bytes);
+	rtc.code(prog, code.data());
+	rtc.destroy(&prog);
+	return true;
+}
+
+bool jit_compile(int device, const std::string &name, const std::string &scene_source, const std::vector<std::string> &var_slots, JitScene &out,
+	std::string &error)
+{
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+	{
+		error = "hipGetDeviceProperties failed";
+		return false;
+	}
+	std::vector<char> code;
+	if (!jit_compile_code(prop.gcnArchName, name, scene_source, var_slots, code, error)) return false;
+
+	JitScene js;
+	js.name = name;
+	hipError_t e = hipModuleLoadData(&js.module, code.data());
+	if (e == hipSuccess) e = hipModuleGetFunction(&js.prepare, js.module, "sdfr_jit_prepare");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js.pixel, js.module, "sdfr_jit_pixel");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js.pixel_debug, js.module, "sdfr_jit_pixel_debug");
+	if (e == hipSuccess) e = hipMalloc((void **)&js.d_frame, sizeof(FrameU));
+	if (e != hipSuccess)
+	{
+		error = std::string("loading the compiled scene failed: ") + hipGetErrorString(e);
+		jit_unload(js);
+		return false;
+	}
+	out = js;
+	return true;
+}
+
+hipError_t jit_prepare(const JitScene &js, FrameU &U, hipStream_t stream)
+{
+	hipError_t e = hipMemcpyAsync(js.d_frame, &U, sizeof U, hipMemcpyHostToDevice, stream);
+	if (e != hipSuccess) return e;
+	FrameU *d = js.d_frame;
+	void *args[] = {&d};
+	e = hipModuleLaunchKernel(js.prepare, 1, 1, 1, 1, 1, 1, 0, stream, args, nullptr);
+	if (e != hipSuccess) return e;
+	e = hipMemcpyAsync(&U, js.d_frame, sizeof U, hipMemcpyDeviceToHost, stream);
+	if (e != hipSuccess) return e;
+	return hipStreamSynchronize(stream);
+}
+
+hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
+{
+	uint32_t n_work = launch_work_items(U.width, rm);
+	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
+	const uint32_t blocks = (n_work + 255u) / 256u;
+	FrameU frame = U;
+	RowMap rows = rm;
+	float *queue = ws.ray_queue;
+	size_t cap = ws.capacity;
+	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &totals, &queue, &cap};
+	return hipModuleLaunchKernel(frame_needs_debug(U) ? js.pixel_debug : js.pixel, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+}
+
+} // namespace sdfr

@@ -9,6 +9,7 @@
 // Per-frame uniform sines/cosines are passed in pre-computed (see Scene::prepare).
 #pragma once
 #include "sdfr_math.h"
+#include "sdfr_frame.h"
 #include "sdfr_noise.h"
 
 namespace sdfr {
@@ -400,5 +401,50 @@ SDF_HD float mat_coordinate_grid(vec3 p, vec3 n, float width)
 	vec3 mask = 1.f - abs(n);
 	return dot(tick, mask);
 }
+
+// ---- helpers every scene shares: checker floor, the standard sun (sdf_common.hlsl:62-94) ------
+// needs SurfacePoint / Material / Light
+// Ray-dependent part of the shared checker floor (sdf_common.hlsl:62-83 via
+// sdf_primitives.hlsl:59-70): the fast plane divides by saturate(dot(dir, -n)) + 1e-20.
+// The division height / denominator is made once per ray into a reciprocal and then done per
+// step with div_c (sdfr_math.h): bit-identical to the IEEE divide for height = 0 and
+// 2^-60 <= |height| <= 2^40 with any denominator in [1e-20, 2] (sdfr_selftest_math what = 3,
+// swept over random and adversarial denominators in tests/test_gpu_math.py).
+struct GroundInv { float denom, rdenom; };
+SDF_HD GroundInv ground_setup(vec3 dir)
+{
+	GroundInv g;
+	g.denom = sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f;
+	g.rdenom = 1.0f / g.denom;
+	return g;
+}
+SDF_HD float ground_dist(vec3 p, bool fast, const GroundInv &g)
+{
+	float d = dot(p, V3(0.f, 1.f, 0.f));
+	return fast ? div_c(d, g.denom, g.rdenom) : d;
+}
+SDF_HD void ground_material(const SurfacePoint &sp, Material &m)
+{
+	if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f))))
+	{
+		vec3 off_right = sp.right_off * sp.camera_distance;
+		vec3 off_bottom = sp.bottom_off * sp.camera_distance;
+		vec3 c = checker_color(sp.pos, sp.dir, off_right, off_bottom);
+		m.diffuse = V4(c.x, c.y, c.z, 1.f);
+		m.specular.x = m.specular.y = m.specular.z = 1.f;
+	}
+}
+// the single white directional light all config scenes but light_shadows use
+SDF_HD bool sun_light(int i, Light &L)
+{
+	if (i != 0) return false;
+	L.pos = V3(-1.f, -1.f, 2.f);
+	L.directional = true;
+	L.color = V3(1.f, 1.f, 1.f);
+	L.extend = 0.f;
+	L.falloff = 0.f;
+	return true;
+}
+SDF_HD void set_rgb(vec4 &c, float v) { c.x = v; c.y = v; c.z = v; }
 
 } // namespace sdfr

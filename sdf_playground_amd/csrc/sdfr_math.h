@@ -12,11 +12,20 @@
 // tests/hostsim builds the per-pixel code on the CPU to bit-compare it with the oracle
 // where no GPU is available.  The product never renders on the CPU.
 #pragma once
+#if !defined(__HIPCC_RTC__) // hiprtc (run-time scene compilation) brings its own runtime declarations
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long size_t;
+#define SDF_HD __host__ __device__ __forceinline__
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SDF_HD __host__ __device__ __forceinline__
 #else

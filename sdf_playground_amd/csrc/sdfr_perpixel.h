@@ -1,154 +1,13 @@
-// sdfr_perpixel.h -- the whole pipeline for ONE pixel, start to finish, on one lane.
-//
-// Used by the "pixel" kernel (one lane per pixel; the simple, divergent schedule kept as the
-// correctness anchor and as the A/B baseline for the wavefront kernels) and by
-// tests/hostsim, which compiles it for the CPU to bit-compare the pipeline stages with the
-// oracle where no GPU is available.  The schedule follows the reference's bounce loop
-// (pshader_sdf.hlsl:286-634) literally.
+// sdfr_perpixel.h -- the per-pixel pipeline (sdfr_render_pixel.h) together with every scene
+// compiled ahead of time, and the registry that numbers them.
 #pragma once
-#include "sdfr_pixel.h"
+#include "sdfr_render_pixel.h"
 #include "sdfr_scenes.h"
 #include "sdfr_scenes2.h"
 #include "sdfr_scenes3.h"
 #include "sdfr_scenes4.h"
 
 namespace sdfr {
-
-struct LocalRayStore
-{
-	RayRec slot[SDFR_MAX_RAYS];
-	SDF_HD void put(int i, const RayRec &r) { slot[i] = r; }
-	SDF_HD RayRec get(int i) const { return slot[i]; }
-};
-
-// Write-behind cache of depth one in front of a ray store: the most recently pushed ray stays
-// in registers and reaches the backing store only when another push follows.  Most pixels
-// spawn a single child (the shadow ray) that is popped right away, so its 44-byte record never
-// travels to HBM and back.
-template <class Backing>
-struct CachedRayStore
-{
-	Backing &backing;
-	RayRec cached;
-	int cached_slot;
-	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
-	SDF_HD void put(int i, const RayRec &r)
-	{
-		if (cached_slot >= 0) backing.put(cached_slot, cached);
-		cached = r;
-		cached_slot = i;
-	}
-	SDF_HD RayRec get(int i)
-	{
-		if (i == cached_slot)
-		{
-			cached_slot = -1;
-			return cached;
-		}
-		return backing.get(i);
-	}
-};
-
-struct PixelCounters
-{
-	uint32_t rays, march_evals, hits;
-#ifdef SDFR_PHASE_CLOCKS
-	// developer build (tools/phase_clocks.py): wave clock spent marching / taking normals / shading
-	uint64_t clk_march, clk_grad, clk_shade, clk_total;
-#endif
-};
-#ifdef SDFR_PHASE_CLOCKS
-#define SDFR_CLK(var) const uint64_t var = __builtin_readcyclecounter()
-#define SDFR_CLK_ADD(field, t0, t1) cnt.field += (t1) - (t0)
-#else
-#define SDFR_CLK(var)
-#define SDFR_CLK_ADD(field, t0, t1)
-#endif
-
-// `store` holds the pixel's pending rays (put/get by slot).  The primary ray never enters
-// it: the reference pops it from slot 0 before anything is pushed (pshader_sdf.hlsl:289-294),
-// so the queue is empty -- and slot 0 free again -- when the first hit is shaded.
-template <class Scene, bool DBG, class Store>
-SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, Store &store)
-{
-	SDFR_CLK(c_begin);
-	const DebugFlags F = debug_flags(U);
-	const PixelRay pr = pixel_ray(U, px, py);
-	RayRec ray = primary_ray(U, pr);
-	uint64_t depths = SDFR_QUEUE_EMPTY;
-	int count = 0; // rays waiting in the store
-
-	float hdr = -1.f;
-	vec3 acc = V3s(0.f);
-	for (int bounce = 0; bounce < U.bounce_count; ++bounce)
-	{
-		if (bounce > 0)
-		{
-			if (count == 0) break;
-			const int idx = queue_next(depths, U.ray_count);
-			ray = store.get(idx);
-			depths = queue_set_depth(depths, idx, RAY_DEPTH_INVALID);
-			--count;
-		}
-		cnt.rays++;
-
-		const typename Scene::RayInv R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
-		const float inside_sign = ray_inside_sign(ray);
-		const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
-
-		SDFR_CLK(c0);
-		March m = march_begin(ray.pos, ray.dir);
-		int status;
-		do
-		{
-			march_pre(m);
-			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
-			cnt.march_evals++;
-			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
-		} while (status == MARCH_CONTINUE);
-		SDFR_CLK(c1);
-		SDFR_CLK_ADD(clk_march, c0, c1);
-
-		vec3 out;
-		if (status == MARCH_HIT)
-		{
-			cnt.hits++;
-			HitInfo hit;
-			hit.pos = march_pos(m);
-			hit.t = m.t;
-			hit.d = m.d;
-			hit.iter = m.iter;
-			const float baseline = m.d * inside_sign;
-			float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			hit.normal = normalize(V3(g0, g1, g2));
-#ifdef SDFR_PHASE_CLOCKS
-			asm volatile("" : "+v"(hit.normal.x), "+v"(hit.normal.y), "+v"(hit.normal.z));
-#endif
-			SDFR_CLK(c2);
-			SDFR_CLK_ADD(clk_grad, c1, c2);
-
-			Spawner<Store> q(store, depths, count, U.ray_count);
-			out = shade_hit<Scene, DBG, Store>(U, F, ray, pr, hit, max_range, hdr, q);
-			depths = q.depths;
-			count = q.count;
-#ifdef SDFR_PHASE_CLOCKS
-			asm volatile("" : "+v"(out.x), "+v"(out.y), "+v"(out.z));
-#endif
-			SDFR_CLK(c3);
-			SDFR_CLK_ADD(clk_shade, c2, c3);
-		}
-		else
-		{
-			out = shade_miss<Scene>(U, ray, m.iter);
-		}
-		acc = acc + out;
-	}
-	SDFR_CLK(c_end);
-	SDFR_CLK_ADD(clk_total, c_begin, c_end);
-	return V4(acc.x, acc.y, acc.z, abs1(hdr));
-}
 
 // scene registry: X(index, SceneType)
 #define SDFR_FOR_EACH_SCENE(X) \

@@ -1,0 +1,174 @@
+// sdfr_pixel_kernel.h -- device side of the PIXEL schedule: one lane per pixel runs the
+// reference's bounce loop start to finish (sdfr_render_pixel.h), waves cover 8x8 pixel tiles,
+// pending rays wait in an HBM queue behind a one-entry register cache.
+//
+// Shared by the kernels compiled ahead of time (sdfr_kernels.hip) and by the translation unit
+// sdfr_jit.cpp builds around a scene compiled at run time (hiprtc), so both run the very same
+// code.  Device compilation only.
+#pragma once
+#include "sdfr_render_pixel.h"
+
+namespace sdfr {
+
+#define SDFR_BLOCK 256
+#define SDFR_INVALID_PIXEL 0xffffffffu
+
+// ---- pixel mapping ------------------------------------------------------------------------------
+// Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
+// neighbouring pixels (coherent materials, similar step counts).  The tile shape is a launch
+// parameter (RowMap::tile_w_log2): 8x8, 16x4, 32x2 or 64x1.
+struct PixelCoord
+{
+	int px, py;   // in the full frame
+	uint32_t pid; // index in this launch's (compact) image
+};
+__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc)
+{
+	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << tw_log2) - 1u) >> tw_log2;
+	const uint32_t tile = w >> 6, lane = w & 63u;
+	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
+	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
+	if (px >= U.width || lrow >= rm.local_rows) return false;
+	const int py = ((lrow >> 3) * rm.world + rm.rank) * 8 + (lrow & 7);
+	if (py >= U.height) return false;
+	pc.px = px;
+	pc.py = py;
+	pc.pid = (uint32_t)lrow * (uint32_t)U.width + (uint32_t)px;
+	return true;
+}
+__device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, uint32_t pid, int &px, int &py)
+{
+	const uint32_t lrow = pid / (uint32_t)U.width;
+	px = (int)(pid - lrow * (uint32_t)U.width);
+	py = (int)(((lrow >> 3) * (uint32_t)rm.world + (uint32_t)rm.rank) * 8u + (lrow & 7u));
+}
+__device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid, vec4 c)
+{
+	if (format == FORMAT_RGBA32F)
+	{
+		reinterpret_cast<float4 *>(out)[pid] = make_float4(c.x, c.y, c.z, c.w);
+	}
+	else
+	{
+		// round-to-nearest-even conversions (v_cvt_f16_f32), two halves per dword
+		const uint32_t hx = __builtin_bit_cast(unsigned short, (_Float16)c.x), hy = __builtin_bit_cast(unsigned short, (_Float16)c.y);
+		const uint32_t hz = __builtin_bit_cast(unsigned short, (_Float16)c.z), hw = __builtin_bit_cast(unsigned short, (_Float16)c.w);
+		uint2 v;
+		v.x = hx | (hy << 16);
+		v.y = hz | (hw << 16);
+		reinterpret_cast<uint2 *>(out)[pid] = v;
+	}
+}
+
+// block-wide sum of three counters into the render totals: one atomic triple per block
+__device__ __forceinline__ void block_add_totals(RenderTotals *totals, uint32_t pixels, uint32_t rays, uint32_t evals, uint32_t hits)
+{
+	__shared__ unsigned long long acc[4];
+	if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+	__syncthreads();
+	// wave reduction by DPP-free shuffles
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		pixels += __shfl_down(pixels, off);
+		rays += __shfl_down(rays, off);
+		evals += __shfl_down(evals, off);
+		hits += __shfl_down(hits, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		atomicAdd(&acc[0], (unsigned long long)pixels);
+		atomicAdd(&acc[1], (unsigned long long)rays);
+		atomicAdd(&acc[2], (unsigned long long)evals);
+		atomicAdd(&acc[3], (unsigned long long)hits);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		if (acc[0]) atomicAdd(&totals->pixels, acc[0]);
+		if (acc[1]) atomicAdd(&totals->rays, acc[1]);
+		if (acc[2]) atomicAdd(&totals->march_evals, acc[2]);
+		if (acc[3]) atomicAdd(&totals->hits, acc[3]);
+	}
+}
+
+// ray record field order in the SoA arrays
+enum { RF_PX = 0, RF_PY, RF_PZ, RF_DX, RF_DY, RF_DZ, RF_CX, RF_CY, RF_CZ, RF_RANGE, RF_BITS, RF_COUNT };
+__device__ __forceinline__ RayRec load_ray(const float *base, size_t cap, uint32_t pid)
+{
+	RayRec r;
+	r.pos = V3(base[RF_PX * cap + pid], base[RF_PY * cap + pid], base[RF_PZ * cap + pid]);
+	r.dir = V3(base[RF_DX * cap + pid], base[RF_DY * cap + pid], base[RF_DZ * cap + pid]);
+	r.contrib = V3(base[RF_CX * cap + pid], base[RF_CY * cap + pid], base[RF_CZ * cap + pid]);
+	r.shadow_range = base[RF_RANGE * cap + pid];
+	r.bits = __float_as_uint(base[RF_BITS * cap + pid]);
+	return r;
+}
+__device__ __forceinline__ void store_ray(float *base, size_t cap, uint32_t pid, const RayRec &r)
+{
+	base[RF_PX * cap + pid] = r.pos.x;
+	base[RF_PY * cap + pid] = r.pos.y;
+	base[RF_PZ * cap + pid] = r.pos.z;
+	base[RF_DX * cap + pid] = r.dir.x;
+	base[RF_DY * cap + pid] = r.dir.y;
+	base[RF_DZ * cap + pid] = r.dir.z;
+	base[RF_CX * cap + pid] = r.contrib.x;
+	base[RF_CY * cap + pid] = r.contrib.y;
+	base[RF_CZ * cap + pid] = r.contrib.z;
+	base[RF_RANGE * cap + pid] = r.shadow_range;
+	base[RF_BITS * cap + pid] = __uint_as_float(r.bits);
+}
+
+// pending rays of one pixel in the HBM queue arrays: [slot][field][pixel], so that lanes
+// holding neighbouring pixels touch neighbouring addresses
+struct GlobalRayStore
+{
+	float *queue;
+	size_t cap;
+	uint32_t pid;
+	__device__ __forceinline__ void put(int slot, const RayRec &r) { store_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid, r); }
+	__device__ __forceinline__ RayRec get(int slot) const { return load_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid); }
+};
+
+// body of the pixel kernel; the __global__ wrappers are k_pixel (scenes compiled ahead of time,
+// sdfr_kernels.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
+template <class Scene, bool DBG>
+__device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
+	RenderTotals *totals, float *ray_queue, size_t cap)
+{
+	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
+	PixelCounters c = {};
+	uint32_t npix = 0;
+	PixelCoord pc;
+	if (w < n_work && work_to_pixel(U, rm, w, pc))
+	{
+		GlobalRayStore backing = {ray_queue, cap, pc.pid};
+		CachedRayStore<GlobalRayStore> store(backing);
+		vec4 v = render_pixel<Scene, DBG, CachedRayStore<GlobalRayStore>>(U, pc.px, pc.py, c, store);
+		store_pixel(out, format, pc.pid, v);
+		if (pixel_stats)
+		{
+			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;
+			pixel_stats[3 * (size_t)pc.pid + 1] = c.march_evals;
+			pixel_stats[3 * (size_t)pc.pid + 2] = c.hits;
+		}
+		npix = 1;
+	}
+#ifdef SDFR_PHASE_CLOCKS
+	// the totals carry wave clocks instead of counts: pixels <- whole pixel loop, rays <- march,
+	// march_evals <- normals, hits <- shading; per wave the lane that stayed longest speaks
+	{
+		uint64_t best = c.clk_total;
+		for (int off = 32; off > 0; off >>= 1) { uint64_t o = __shfl_xor(best, off); best = o > best ? o : best; }
+		const uint64_t first = __ballot(c.clk_total == best);
+		const bool speaker = (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(first);
+		block_add_totals(totals, speaker ? (uint32_t)(c.clk_total >> 4) : 0u, speaker ? (uint32_t)(c.clk_march >> 4) : 0u,
+			speaker ? (uint32_t)(c.clk_grad >> 4) : 0u, speaker ? (uint32_t)(c.clk_shade >> 4) : 0u);
+		return;
+	}
+#endif
+	block_add_totals(totals, npix, c.rays, c.march_evals, c.hits);
+}
+
+} // namespace sdfr

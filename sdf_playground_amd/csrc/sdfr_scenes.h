@@ -20,55 +20,12 @@
 
 namespace sdfr {
 
-// Ray-dependent part of the shared checker floor (sdf_common.hlsl:62-83 via
-// sdf_primitives.hlsl:59-70): the fast plane divides by saturate(dot(dir, -n)) + 1e-20.
-// The division height / denominator is made once per ray into a reciprocal and then done per
-// step with div_c (sdfr_math.h): bit-identical to the IEEE divide for height = 0 and
-// 2^-60 <= |height| <= 2^40 with any denominator in [1e-20, 2] (sdfr_selftest_math what = 3,
-// swept over random and adversarial denominators in tests/test_gpu_math.py).
-struct GroundInv { float denom, rdenom; };
-SDF_HD GroundInv ground_setup(vec3 dir)
-{
-	GroundInv g;
-	g.denom = sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f;
-	g.rdenom = 1.0f / g.denom;
-	return g;
-}
-SDF_HD float ground_dist(vec3 p, bool fast, const GroundInv &g)
-{
-	float d = dot(p, V3(0.f, 1.f, 0.f));
-	return fast ? div_c(d, g.denom, g.rdenom) : d;
-}
-SDF_HD void ground_material(const SurfacePoint &sp, Material &m)
-{
-	if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f))))
-	{
-		vec3 off_right = sp.right_off * sp.camera_distance;
-		vec3 off_bottom = sp.bottom_off * sp.camera_distance;
-		vec3 c = checker_color(sp.pos, sp.dir, off_right, off_bottom);
-		m.diffuse = V4(c.x, c.y, c.z, 1.f);
-		m.specular.x = m.specular.y = m.specular.z = 1.f;
-	}
-}
-// the single white directional light all config scenes but light_shadows use
-SDF_HD bool sun_light(int i, Light &L)
-{
-	if (i != 0) return false;
-	L.pos = V3(-1.f, -1.f, 2.f);
-	L.directional = true;
-	L.color = V3(1.f, 1.f, 1.f);
-	L.extend = 0.f;
-	L.falloff = 0.f;
-	return true;
-}
-SDF_HD void set_rgb(vec4 &c, float v) { c.x = v; c.y = v; c.z = v; }
-
 // =========================================================================================
 struct SceneFastSphere
 {
 	static const char *name() { return "fast_sphere"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -100,7 +57,7 @@ struct SceneCubeSea
 {
 	static const char *name() { return "cube_sea"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; vec2 barrier; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -166,7 +123,7 @@ struct SceneLabyrinth
 	static const char *name() { return "labyrinth"; }
 	static const char *variables() { return ""; }
 	enum { SU_FIRE_SCROLL = 0 };
-	static void prepare(FrameU &U) { U.su[SU_FIRE_SCROLL] = U.stime * 3.f; }
+	static SDF_HD void prepare(FrameU &U) { U.su[SU_FIRE_SCROLL] = U.stime * 3.f; }
 
 	static SDF_HD float fire_cone(vec3 p) { return sd_round_cone(p, V3(0.f, 1.1f, 0.f), V3(0.f, 1.6f, 0.f), 0.15f, 0.1f); }
 
@@ -308,7 +265,7 @@ struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -378,15 +335,15 @@ struct SceneFractal
 struct SceneLense
 {
 	static const char *name() { return "lense"; }
-	// the scene's VAR_ tags in source order; slot k of FrameU::scene_var is the k-th distinct name
+	// the scene's variable tags in source order; slot k of FrameU::scene_var is the k-th distinct name
 	static const char *variables()
 	{
 		return "VAR_xpos(min = -4, max = 4, step = 0.1) VAR_ypos(min = -4, max = 4, step = 0.1) "
 			   "VAR_zpos(min = 0, max = 25, step = 0.1) VAR_mixing(min = 0, max = 1, step = 0.05)";
 	}
-	enum { VAR_XPOS = 0, VAR_YPOS = 1, VAR_ZPOS = 2, VAR_MIXING = 3 };
+	enum { SV_XPOS = 0, SV_YPOS = 1, SV_ZPOS = 2, SV_MIXING = 3 };
 	enum { SU_MIRROR_S = 0, SU_MIRROR_C = 1 };
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		vec2 sc = sincos1(U.stime * 0.3f);
 		U.su[SU_MIRROR_S] = sc.x;
@@ -416,7 +373,7 @@ struct SceneLense
 		lp.z = lp.z - 5.1f;
 		o.lense = max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f));
 
-		o.sphere = sd_sphere(p - V3(U.scene_var[VAR_XPOS], U.scene_var[VAR_YPOS], U.scene_var[VAR_ZPOS]), 2.f);
+		o.sphere = sd_sphere(p - V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]), 2.f);
 
 		vec3 mp = p - V3(0.f, 0.f, -5.f);
 		vec2 mr = rot2(V2(mp.x, mp.z), U.su[SU_MIRROR_S], U.su[SU_MIRROR_C]);
@@ -471,7 +428,7 @@ struct SceneLense
 		else if (on_surface(o.mirror))
 		{
 			m.diffuse = V4(0.1f, 0.1f, 0.1f, 1.f);
-			float mix = U.scene_var[VAR_MIXING];
+			float mix = U.scene_var[SV_MIXING];
 			m.refraction = V3s(mix);
 			m.reflection = V3s(1.f - mix);
 		}
@@ -493,7 +450,7 @@ struct SceneGems
 	static const char *name() { return "gems"; }
 	static const char *variables() { return ""; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		vec2 sc = sincos1(U.stime * 0.5f);
 		U.su[SU_ROT_S] = sc.x;
@@ -557,7 +514,7 @@ struct SceneLightShadows
 		vec3 c = hsv_to_rgb(V3(h, 1.f, 1.f));
 		return c / rgb_to_brightness(c);
 	}
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		float time = U.stime * 0.25f;
 		for (uint32_t i = 0; i < 5; ++i)

@@ -19,7 +19,7 @@ struct SceneCube
 			   "VAR_red(min = 0, max = 1, start = 0.9, step = 0.05) VAR_green(min = 0, max = 1, start = 0.7, step = 0.05) "
 			   "VAR_blue(min = 0, max = 1, start = 0.2, step = 0.05)";
 	}
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -56,7 +56,7 @@ struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { int unused; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
 	// a gyroid shell clipped to the unit cube; no floor in this scene
@@ -89,7 +89,7 @@ struct SceneBasicTransparency
 {
 	static const char *name() { return "basic_transparency"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	static SDF_HD float pane(vec3 p, float z) { return sd_box(p - V3(0.f, 2.f, z), V3(1.f, 1.f, 0.1f)); }
 	// a ray continuing through a pane ignores the pane it just left (OBJECT_TRANSPARENT)
 	struct RayInv { GroundInv ground; bool skip1, skip2, skip3; };
@@ -131,7 +131,7 @@ struct SceneBasicClouds
 {
 	static const char *name() { return "basic_clouds"; }
 	static const char *variables() { return "VAR_offset(min = -5, max = 5, step = 0.05)"; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	static SDF_HD float slab(vec3 p) { return sd_box(p - V3(0.f, 5.f, 0.f), V3(2.f, 0.5f, 2.f)); }
 	struct RayInv { GroundInv ground; bool skip_cloud; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
@@ -185,7 +185,7 @@ struct SceneCoordinateMaterial
 		return "VAR_boxoffset(min = 0, max = 2, step = 0.1, start = 2) VAR_spherical(min = 0, max = 1, step = 1, start = 0) "
 			   "VAR_thres(min=0,max=1,step=0.05, start=0.4)";
 	}
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -242,7 +242,7 @@ struct SceneDistortion
 {
 	static const char *name() { return "distortion"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -303,7 +303,7 @@ struct SceneTable
 {
 	static const char *name() { return "table"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -370,7 +370,7 @@ struct SceneSierpinski
 {
 	static const char *name() { return "sierpinski"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -430,7 +430,7 @@ struct SceneNeon
 			   "VAR_blue(min = 0, max = 3, start = 0.2, step = 0.05)";
 	}
 	enum { SU_MIRROR_S = 0, SU_MIRROR_C = 1 };
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		const vec2 sc = sincos1(0.3f); // the mirror's fixed yaw
 		U.su[SU_MIRROR_S] = sc.x;

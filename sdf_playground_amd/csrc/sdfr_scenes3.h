@@ -11,7 +11,7 @@ struct SceneFractal2
 	static const char *name() { return "fractal2"; }
 	static const char *variables() { return "VAR_slider(min = -5, max = 5, step = 0.01, start = 0)"; } // declared, unused by the scene
 	enum { SU_SLICE_SHIFT = 0 };
-	static void prepare(FrameU &U) { U.su[SU_SLICE_SHIFT] = U.stime * 0.5f; }
+	static SDF_HD void prepare(FrameU &U) { U.su[SU_SLICE_SHIFT] = U.stime * 0.5f; }
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -89,7 +89,7 @@ struct SceneShell
 {
 	static const char *name() { return "shell"; }
 	static const char *variables() { return ""; }
-	static void prepare(FrameU &) {}
+	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
@@ -138,7 +138,7 @@ struct SceneSpiral
 	static const char *variables() { return ""; }
 	// a spring hopping along a parabola: everything about the hop is frame-uniform
 	enum { SU_SHIFT_X = 0, SU_SPRING_S, SU_SPRING_C, SU_CENTER_Y, SU_LENGTH };
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		const float speed = 1.5f, width = 4.f, height = 6.f, pen = 2.f;
 		float spring_length = 3.f;
@@ -217,7 +217,7 @@ struct SceneTerrain
 	static const char *name() { return "terrain"; }
 	static const char *variables() { return "VAR_levels(min=1, max=10, step=1, start=2)"; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
-	static void prepare(FrameU &U)
+	static SDF_HD void prepare(FrameU &U)
 	{
 		const vec2 sc = sincos1(1.f); // the fixed twist between octaves
 		U.su[SU_ROT_S] = sc.x;
@@ -293,7 +293,7 @@ struct SceneTiling
 			   "VAR_truchet_width(min = 0, max = 0.2, step = 0.01)";
 	}
 	enum { SU_PULSE = 0 };
-	static void prepare(FrameU &U) { U.su[SU_PULSE] = U.stime * 2.f; }
+	static SDF_HD void prepare(FrameU &U) { U.su[SU_PULSE] = U.stime * 2.f; }
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{

@@ -11,7 +11,7 @@ struct SceneTree
 	static const char *name() { return "tree"; }
 	static const char *variables() { return ""; }
 	enum { SU_DRIFT = 0 };
-	static void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
+	static SDF_HD void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
 
 	struct RayInv { GroundInv ground; vec2 dir2; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)

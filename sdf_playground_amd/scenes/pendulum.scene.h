@@ -1,0 +1,80 @@
+// pendulum.scene.h -- example of a scene compiled at run time (scenes/README.md):
+// checker floor, a mirror ball swinging on a rod from a wooden gallows, one sun.
+//   python -m sdf_playground_amd.cli --scene-source sdf_playground_amd/scenes/pendulum.scene.h --out pendulum.png
+struct Scene
+{
+	enum { SU_SWING_S = 0, SU_SWING_C = 1 };
+	static SDF_HD void prepare(FrameU &U)
+	{
+		// swing angle: amplitude * sin(time)
+		const float angle = VAR_swing(min = 0, max = 1.2, start = 0.7) * sin1(U.stime * 1.5f);
+		const vec2 sc = sincos1(angle);
+		U.su[SU_SWING_S] = sc.x;
+		U.su[SU_SWING_C] = sc.y;
+	}
+
+	struct RayInv { GroundInv ground; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	{
+		RayInv r;
+		r.ground = ground_setup(dir);
+		return r;
+	}
+
+	// position in the pendulum's frame: pivot at the origin, rod along -y
+	static SDF_HD vec3 swing_frame(const FrameU &U, vec3 p)
+	{
+		const vec3 q = p - V3(0.f, 3.f, 0.f);
+		const vec2 r = rot2(V2(q.x, q.y), U.su[SU_SWING_S], U.su[SU_SWING_C]);
+		return V3(r.x, r.y, q.z);
+	}
+	static SDF_HD float ball(const FrameU &U, vec3 p)
+	{
+		const float len = VAR_rod(min = 0.5, max = 2.5, start = 1.8);
+		return sd_sphere(swing_frame(U, p) + V3(0.f, len, 0.f), VAR_radius(min = 0.1, max = 0.8, start = 0.45));
+	}
+	static SDF_HD float rod(const FrameU &U, vec3 p)
+	{
+		const float len = VAR_rod(min = 0.5, max = 2.5, start = 1.8);
+		return sd_capped_cylinder(swing_frame(U, p) + V3(0.f, len * 0.5f, 0.f), len * 0.5f, 0.03f);
+	}
+	static SDF_HD float gallows(vec3 p)
+	{
+		const float post = sd_box(p - V3(-1.5f, 1.6f, 0.f), V3(0.1f, 1.6f, 0.1f));
+		const float beam = sd_box(p - V3(-0.6f, 3.1f, 0.f), V3(1.f, 0.1f, 0.1f));
+		return op_chamfer_merge(post, beam, 0.1f);
+	}
+
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
+	{
+		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		d = min1(d, ball(U, p));
+		d = min1(d, rod(U, p));
+		return min1(d, gallows(p));
+	}
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
+	{
+		ground_material(sp, m);
+		if (on_surface(ball(U, sp.pos)))
+		{
+			m.diffuse = V4(0.05f, 0.05f, 0.08f, 1.f);
+			set_rgb(m.specular, 1.f);
+			m.reflection = V3s(0.7f);
+		}
+		if (on_surface(rod(U, sp.pos)))
+		{
+			m.diffuse = V4(0.6f, 0.6f, 0.65f, 1.f);
+			set_rgb(m.specular, 1.f);
+		}
+		if (on_surface(gallows(sp.pos)))
+		{
+			m.id = MAT_WOOD;
+			m.mpos = sp.pos * 2.f;
+			m.diffuse = V4(0.f, 0.f, 0.f, 1.f);
+			set_rgb(m.specular, 0.2f);
+		}
+	}
+	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD float ambient() { return 0.075f; }
+	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
+};
