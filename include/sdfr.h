@@ -161,6 +161,20 @@ typedef struct sdfr_stats
 /* waits for the last render, then reports it */
 int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out);
 
+/* ---- named GPU timings: GPUProfiler::profile/getResults (GPUProfiler.h:12-35) with the names the
+ *      reference's frame uses ("setup", "draw" SDFRenderer.cpp:100-104; "Bloom 1", "Bloom 2", "HDR"
+ *      Postprocessing.cpp:147-171).  "setup" is host time (uniform latch); the vertical blur and
+ *      the tone map are one kernel here and report as "Bloom 2 + HDR"; with sdfr_set_profiling the
+ *      wavefront schedule adds "draw: march k" / "draw: shade k".  Covers the last sdfr_render* and
+ *      the last sdfr_postprocess; waits for them.  Returns the number of entries available (may
+ *      exceed `capacity`; only `capacity` are written), or a negative status. ------------------- */
+typedef struct sdfr_timing
+{
+	char name[32];
+	double ms;
+} sdfr_timing;
+int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity);
+
 /* ---- self-test of the kernels' fast exact arithmetic (no reference counterpart) ---------------
  * The kernels replace hipcc's generic correctly rounded fp32 sqrt, and divisions by scene
  * constants, with shorter sequences that give the SAME correctly rounded bits on their stated

@@ -46,6 +46,10 @@ class _CVariable(ctypes.Structure):
                 ("step", ctypes.c_float), ("value", ctypes.c_float)]
 
 
+class _CTiming(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("ms", ctypes.c_double)]
+
+
 class Limits(ctypes.Structure):
     """sdfr_limits: the driver's compile-time limits (pshader_sdf.hlsl:60-64,350) at run time."""
 
@@ -65,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings",
 ]
 
 _lib = None
@@ -128,6 +132,7 @@ def load_library():
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
     L.sdfr_sync.argtypes = [vp]
     L.sdfr_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.sdfr_get_timings.argtypes = [vp, ctypes.POINTER(_CTiming), ci]
     L.sdfr_postprocess.argtypes = [vp, ci, ci, vp, vp, vp]
     L.sdfr_selftest_math.argtypes = [vp, ci, cf, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
@@ -363,6 +368,14 @@ class SDFRenderer:
         self._check(self._L.sdfr_assemble_strips(self._h, width, height, world, ctypes.c_void_p(gathered.data_ptr()),
                                                  ctypes.c_void_p(out.data_ptr()), fmt))
         return out
+
+    def getTimings(self):
+        """GPUProfiler::getResults: {name: ms} of the last render and the last postprocess, in frame order."""
+        buf = (_CTiming * 48)()
+        n = self._L.sdfr_get_timings(self._h, buf, 48)
+        if n < 0:
+            self._check(n)
+        return {buf[i].name.decode(): buf[i].ms for i in range(min(n, 48))}
 
     def postprocess(self, scene16, bloom_scratch, out8):
         """HDR::process on device tensors: scene16/bloom_scratch [H,W,4] float16, out8 [H,W,4] uint8."""

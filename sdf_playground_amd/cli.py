@@ -149,6 +149,7 @@ def main(argv=None):
         write_png(a.out, hdr.process().cpu().numpy())
     s = r.getStats()
     print("%s %dx%d: %.3f ms, %d rays (%.1f Mrays/s)" % (a.scene, w, h, s.ms_gpu, s.rays, s.rays / max(s.ms_gpu, 1e-9) / 1e3))
+    print("  ".join("%s %.3f ms" % kv for kv in r.getTimings().items()))
     r.close()
     return 0
 

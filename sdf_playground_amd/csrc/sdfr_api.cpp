@@ -10,6 +10,7 @@
 #include "sdfr_jit.h"
 #include "sdfr_kernels.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,9 @@ struct sdfr_renderer
 	size_t pstat_bytes = 0;
 
 	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	hipEvent_t ev_post[3] = {}; // before / between / after the two post-processing kernels
+	bool have_post = false;
+	double ms_setup = 0.0;      // host time of the last latch_frame (+ Scene::prepare of a run-time scene)
 	hipEvent_t ev_march[32] = {}, ev_shade[32] = {};
 	int last_rounds = 0;
 	bool have_render = false;
@@ -141,6 +145,7 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 	}
 	for (int i = 0; i < 32; ++i)
 	{
+		if (i < 3) hipEventCreate(&r->ev_post[i]);
 		hipEventCreate(&r->ev_march[i]);
 		hipEventCreate(&r->ev_shade[i]);
 	}
@@ -160,6 +165,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	hipFree(r->d_pstat);
 	hipEventDestroy(r->ev_begin);
 	hipEventDestroy(r->ev_end);
+	for (hipEvent_t e : r->ev_post) hipEventDestroy(e);
 	for (int i = 0; i < 32; ++i)
 	{
 		hipEventDestroy(r->ev_march[i]);
@@ -457,9 +463,11 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
 	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	if (world < 1 || rank < 0 || rank >= world) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad rank/world");
+	SDFR_HIP(hipSetDevice(r->device));
+	const auto t_setup = std::chrono::steady_clock::now();
 	int rc = latch_frame(r, width, height);
 	if (rc != SDFR_OK) return rc;
-	SDFR_HIP(hipSetDevice(r->device));
+	r->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup).count();
 
 	RowMap rm;
 	rm.rank = rank;
@@ -559,8 +567,11 @@ int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_
 	if (!r || !scene_rgba16f || !bloom_scratch_rgba16f || !out_rgba8) return SDFR_ERR_INVALID_ARGUMENT;
 	if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
 	SDFR_HIP(hipSetDevice(r->device));
-	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->stream);
+	SDFR_HIP(hipEventRecord(r->ev_post[0], r->stream));
+	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->stream, r->ev_post[1]);
 	if (e != hipSuccess) return hip_fail(r, e, "postprocess launch");
+	SDFR_HIP(hipEventRecord(r->ev_post[2], r->stream));
+	r->have_post = true;
 	return SDFR_OK;
 }
 
@@ -620,6 +631,50 @@ int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out)
 		out->march_launches = 1;
 	}
 	return SDFR_OK;
+}
+
+int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity)
+{
+	if (!r || (!out && capacity > 0) || capacity < 0) return SDFR_ERR_INVALID_ARGUMENT;
+	int n = 0;
+	auto put = [&](const char *name, double ms) {
+		if (n < capacity)
+		{
+			memset(&out[n], 0, sizeof out[n]);
+			snprintf(out[n].name, sizeof out[n].name, "%s", name);
+			out[n].ms = ms;
+		}
+		++n;
+	};
+	if (r->have_render)
+	{
+		SDFR_HIP(hipEventSynchronize(r->ev_end));
+		float ms = 0.f;
+		SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
+		put("setup", r->ms_setup);
+		put("draw", ms);
+		for (int i = 0; r->last_wavefront && r->last_profiled && i < r->last_rounds && i < 16; ++i)
+		{
+			float a = 0.f, b = 0.f;
+			char nm[32];
+			if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) != hipSuccess) continue;
+			if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) != hipSuccess) continue;
+			snprintf(nm, sizeof nm, "draw: march %d", i);
+			put(nm, a);
+			snprintf(nm, sizeof nm, "draw: shade %d", i);
+			put(nm, b);
+		}
+	}
+	if (r->have_post)
+	{
+		SDFR_HIP(hipEventSynchronize(r->ev_post[2]));
+		float a = 0.f, b = 0.f;
+		SDFR_HIP(hipEventElapsedTime(&a, r->ev_post[0], r->ev_post[1]));
+		SDFR_HIP(hipEventElapsedTime(&b, r->ev_post[1], r->ev_post[2]));
+		put("Bloom 1", a);
+		put("Bloom 2 + HDR", b); // the vertical blur and the tone map are one kernel here
+	}
+	return n;
 }
 
 } // extern "C"

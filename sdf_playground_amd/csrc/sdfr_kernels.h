@@ -33,7 +33,8 @@ hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &r
 hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream);
 
 // HDR::process: scene16/bloom1 RGBA16F, ldr8 RGBA8, all device pointers of width*height pixels
-hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, hipStream_t stream);
+// mid_event (optional) is recorded between the two kernels
+hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, hipStream_t stream, hipEvent_t mid_event = nullptr);
 
 hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream);
 

@@ -126,10 +126,11 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 	}
 }
 
-hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, hipStream_t stream)
+hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, hipStream_t stream, hipEvent_t mid_event)
 {
 	dim3 g1((width + 255) / 256, height);
 	hipLaunchKernelGGL(k_bloom_h, g1, dim3(256), 0, stream, reinterpret_cast<const uint2 *>(scene16), reinterpret_cast<uint2 *>(bloom1), width, height);
+	if (mid_event) (void)hipEventRecord(mid_event, stream);
 	dim3 g2((width + POST_TX - 1) / POST_TX, (height + POST_TY - 1) / POST_TY);
 	hipLaunchKernelGGL(k_bloom_v_tone, g2, dim3(256), 0, stream, reinterpret_cast<const uint2 *>(scene16), reinterpret_cast<const uint2 *>(bloom1),
 		reinterpret_cast<uint32_t *>(ldr8), width, height);

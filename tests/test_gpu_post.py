@@ -63,3 +63,28 @@ def test_postprocess_of_rendered_frame(renderer, oracle):
     _, _, ref = oracle.postprocess(scene16)
     assert np.array_equal(ldr, ref)
     assert (ldr[..., :3].max(axis=2) > 200).mean() > 0.002  # something bright is in the picture
+
+
+def test_named_timings_follow_the_reference_frame():
+    """GPUProfiler names of one frame (SDFRenderer.cpp:100-104, Postprocessing.cpp:147-171)."""
+    import sdf_playground_amd as sp
+    import torch
+
+    r = sp.SDFRenderer(0)
+    r.initShader("labyrinth")
+    assert r.getTimings() == {}
+    hdr = sp.HDR(r)
+    hdr.init(320, 200)
+    r.render(sp.Camera(), 320, 200, out=hdr.getRenderTarget(), fmt=sp.RGBA16F)
+    assert list(r.getTimings()) == ["setup", "draw"]
+    hdr.process()
+    t = r.getTimings()
+    assert list(t) == ["setup", "draw", "Bloom 1", "Bloom 2 + HDR"]
+    assert all(v >= 0.0 for v in t.values()) and t["draw"] > 0.0 and t["Bloom 1"] > 0.0
+    assert abs(t["draw"] - r.getStats().ms_gpu) < 1e-6
+    r.setSchedule(sp.SCHEDULE_WAVEFRONT)
+    r.setProfiling(True)
+    r.render(sp.Camera(), 320, 200, out=hdr.getRenderTarget(), fmt=sp.RGBA16F)
+    names = list(r.getTimings())
+    assert names[:4] == ["setup", "draw", "draw: march 0", "draw: shade 0"] and names[-2:] == ["Bloom 1", "Bloom 2 + HDR"]
+    r.close()
