@@ -74,15 +74,16 @@ static int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
 static void free_workspace(sdfr_renderer *r)
 {
 	WavefrontWorkspace &w = r->ws;
-	hipFree(w.ray_cur);
-	hipFree(w.ray_queue);
-	hipFree(w.qdepth_lo);
-	hipFree(w.qdepth_hi);
-	hipFree(w.result);
-	hipFree(w.accum);
-	hipFree(w.list_a);
-	hipFree(w.list_b);
-	hipFree(w.counters);
+	(void)hipFree(w.ray_cur);
+	(void)hipFree(w.ray_queue);
+	(void)hipFree(w.qdepth_lo);
+	(void)hipFree(w.qdepth_hi);
+	(void)hipFree(w.result);
+	(void)hipFree(w.accum);
+	(void)hipFree(w.list_a);
+	(void)hipFree(w.list_b);
+	(void)hipFree(w.counters);
+	(void)hipFree(w.partials);
 	w = WavefrontWorkspace{};
 }
 
@@ -101,6 +102,7 @@ static int ensure_workspace(sdfr_renderer *r, size_t pixels)
 	SDFR_HIP(hipMalloc((void **)&w.list_a, sizeof(uint32_t) * pixels));
 	SDFR_HIP(hipMalloc((void **)&w.list_b, sizeof(uint32_t) * pixels));
 	SDFR_HIP(hipMalloc((void **)&w.counters, sizeof(uint32_t) * 64));
+	SDFR_HIP(hipMalloc((void **)&w.partials, sizeof(RenderTotals) * (pixels / 256 + 1)));
 	w.pstat = nullptr;
 	r->ws = w;
 	return SDFR_OK;
@@ -145,9 +147,9 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 	}
 	for (int i = 0; i < 32; ++i)
 	{
-		if (i < 3) hipEventCreate(&r->ev_post[i]);
-		hipEventCreate(&r->ev_march[i]);
-		hipEventCreate(&r->ev_shade[i]);
+		if (i < 3) (void)hipEventCreate(&r->ev_post[i]);
+		(void)hipEventCreate(&r->ev_march[i]);
+		(void)hipEventCreate(&r->ev_shade[i]);
 	}
 	*out = r;
 	return SDFR_OK;
@@ -156,20 +158,20 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 void sdfr_destroy(sdfr_renderer *r)
 {
 	if (!r) return;
-	hipSetDevice(r->device);
-	hipStreamSynchronize(r->stream);
+	(void)hipSetDevice(r->device);
+	(void)hipStreamSynchronize(r->stream);
 	free_workspace(r);
 	jit_unload(r->jit);
-	hipFree(r->d_totals);
-	hipFree(r->d_stage);
-	hipFree(r->d_pstat);
-	hipEventDestroy(r->ev_begin);
-	hipEventDestroy(r->ev_end);
-	for (hipEvent_t e : r->ev_post) hipEventDestroy(e);
+	(void)hipFree(r->d_totals);
+	(void)hipFree(r->d_stage);
+	(void)hipFree(r->d_pstat);
+	(void)hipEventDestroy(r->ev_begin);
+	(void)hipEventDestroy(r->ev_end);
+	for (hipEvent_t e : r->ev_post) (void)hipEventDestroy(e);
 	for (int i = 0; i < 32; ++i)
 	{
-		hipEventDestroy(r->ev_march[i]);
-		hipEventDestroy(r->ev_shade[i]);
+		(void)hipEventDestroy(r->ev_march[i]);
+		(void)hipEventDestroy(r->ev_shade[i]);
 	}
 	delete r;
 }
@@ -484,7 +486,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	{
 		if (r->stage_bytes < local_pixels * bpp)
 		{
-			hipFree(r->d_stage);
+			(void)hipFree(r->d_stage);
 			r->d_stage = nullptr;
 			r->stage_bytes = 0;
 			SDFR_HIP(hipMalloc(&r->d_stage, local_pixels * bpp));
@@ -495,7 +497,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 		{
 			if (r->pstat_bytes < local_pixels * 12)
 			{
-				hipFree(r->d_pstat);
+				(void)hipFree(r->d_pstat);
 				r->d_pstat = nullptr;
 				r->pstat_bytes = 0;
 				SDFR_HIP(hipMalloc((void **)&r->d_pstat, local_pixels * 12));

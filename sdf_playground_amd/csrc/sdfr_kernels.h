@@ -21,6 +21,7 @@ struct WavefrontWorkspace
 	uint32_t *list_a;    // [capacity] pixels with a ray in flight (ping)
 	uint32_t *list_b;    // [capacity] (pong)
 	uint32_t *counters;  // [64] list sizes per round and misc
+	RenderTotals *partials; // [capacity / 256 + 1] per-block counter sums of the pixel schedule
 };
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
@@ -37,6 +38,8 @@ hipError_t launch_assemble_strips(int width, int height, int world, const void *
 hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, hipStream_t stream, hipEvent_t mid_event = nullptr);
 
 hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream);
+
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream);
 
 int device_cu_count(int device);
 // work items (padded to whole tiles) of a launch: lists and per-pixel state are sized by this

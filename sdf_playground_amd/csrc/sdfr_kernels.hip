@@ -49,9 +49,38 @@ static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_wo
 // =================================================================================================
 template <class Scene, bool DBG>
 __global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, float *ray_queue, size_t cap)
+	RenderTotals *partials, float *ray_queue, size_t cap)
 {
-	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, totals, ray_queue, cap);
+	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, ray_queue, cap);
+}
+
+// folds the per-block partial sums of a pixel-schedule launch into the render totals
+__global__ __launch_bounds__(SDFR_BLOCK) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals)
+{
+	__shared__ unsigned long long acc[SDFR_BLOCK][4];
+	unsigned long long s[4] = {0ull, 0ull, 0ull, 0ull};
+	for (uint32_t i = threadIdx.x; i < n; i += SDFR_BLOCK)
+	{
+		const RenderTotals p = partials[i];
+		s[0] += p.pixels;
+		s[1] += p.rays;
+		s[2] += p.march_evals;
+		s[3] += p.hits;
+	}
+	for (int k = 0; k < 4; ++k) acc[threadIdx.x][k] = s[k];
+	__syncthreads();
+	for (int off = SDFR_BLOCK / 2; off > 0; off >>= 1)
+	{
+		if ((int)threadIdx.x < off)
+			for (int k = 0; k < 4; ++k) acc[threadIdx.x][k] += acc[threadIdx.x + off][k];
+		__syncthreads();
+	}
+	if (threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] += acc[0][threadIdx.x];
+}
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_reduce_totals, dim3(1), dim3(SDFR_BLOCK), 0, stream, partials, n_blocks, totals);
+	return hipGetLastError();
 }
 
 // =================================================================================================
@@ -403,9 +432,9 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
 	const uint32_t blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, totals, ws.ray_queue,
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, ws.ray_queue,
 		ws.capacity);
-	return hipGetLastError();
+	return launch_reduce_totals(ws.partials, blocks, totals, stream);
 }
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,

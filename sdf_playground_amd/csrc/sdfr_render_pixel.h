@@ -50,7 +50,7 @@ struct PixelCounters
 	uint32_t rays, march_evals, hits;
 #ifdef SDFR_PHASE_CLOCKS
 	// developer build (tools/phase_clocks.py): wave clock spent marching / taking normals / shading
-	uint64_t clk_march, clk_grad, clk_shade, clk_total;
+	uint64_t clk_march, clk_grad, clk_shade, clk_miss, clk_total;
 #endif
 };
 #ifdef SDFR_PHASE_CLOCKS
@@ -138,6 +138,11 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		else
 		{
 			out = shade_miss<Scene>(U, ray, m.iter);
+#ifdef SDFR_PHASE_CLOCKS
+			asm volatile("" : "+v"(out.x), "+v"(out.y), "+v"(out.z));
+#endif
+			SDFR_CLK(c4);
+			SDFR_CLK_ADD(clk_miss, c1, c4);
 		}
 		acc = acc + out;
 	}

@@ -1,7 +1,7 @@
 """Developer tool: where does a wave of the pixel kernel spend its clocks?
 
 Builds libsdfr with -DSDFR_PHASE_CLOCKS into gpurun_out/libsdfr_clocks.so (the render totals
-then carry wave clocks: whole pixel loop / marching / normals / shading, from the lane of each
+then carry wave clocks: whole pixel loop / marching / background / normals + shading, from the lane of each
 wave that stayed longest) and prints the split for a few frames.  Not a product build.
 
   python tools/phase_clocks.py --build          (here: cross-compile)
@@ -45,7 +45,7 @@ def main():
         s = r.getStats()
         tot = max(1, s.pixels)
         other = s.pixels - s.rays - s.march_evals - s.hits
-        print("%s frame %d: %.3f ms; wave clocks: march %.1f%%, normals %.1f%%, shading %.1f%%, queue/other %.1f%%" % (
+        print("%s frame %d: %.3f ms; wave clocks: march %.1f%%, background %.1f%%, normals+shading %.1f%%, queue/other %.1f%%" % (
             a.scene, k, s.ms_gpu, 100.0 * s.rays / tot, 100.0 * s.march_evals / tot, 100.0 * s.hits / tot, 100.0 * other / tot), flush=True)
     r.close()
 
