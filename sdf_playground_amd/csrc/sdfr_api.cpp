@@ -509,7 +509,8 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	if (world > 1) // strips past the end of the frame are never written: define them
 		SDFR_HIP(hipMemsetAsync(d_out, 0, local_pixels * bpp, r->stream));
 
-	SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream));
+	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
+	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;
 	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm));
 	if (rc != SDFR_OK) return rc;

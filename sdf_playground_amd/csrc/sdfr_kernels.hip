@@ -54,32 +54,46 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_pixel(FrameU U, RowMap rm, uint3
 	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, ray_queue, cap);
 }
 
-// folds the per-block partial sums of a pixel-schedule launch into the render totals
-__global__ __launch_bounds__(SDFR_BLOCK) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals)
+// folds the per-block partial sums of a pixel-schedule launch into the render totals (overwrites
+// them: no memset needed).  One block; every thread keeps 8 independent 32-byte loads in flight,
+// so the ~1 MB of partials of a 4K frame takes a few microseconds instead of a chain of
+// dependent round trips.
+#define SDFR_REDUCE_THREADS 1024
+__global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals)
 {
-	__shared__ unsigned long long acc[SDFR_BLOCK][4];
-	unsigned long long s[4] = {0ull, 0ull, 0ull, 0ull};
-	for (uint32_t i = threadIdx.x; i < n; i += SDFR_BLOCK)
-	{
-		const RenderTotals p = partials[i];
-		s[0] += p.pixels;
-		s[1] += p.rays;
-		s[2] += p.march_evals;
-		s[3] += p.hits;
-	}
-	for (int k = 0; k < 4; ++k) acc[threadIdx.x][k] = s[k];
+	__shared__ unsigned long long acc[4];
+	if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
 	__syncthreads();
-	for (int off = SDFR_BLOCK / 2; off > 0; off >>= 1)
+	unsigned long long s[4] = {0ull, 0ull, 0ull, 0ull};
+	const ulonglong4 *src = reinterpret_cast<const ulonglong4 *>(partials);
+	for (uint32_t base = threadIdx.x; base < n; base += SDFR_REDUCE_THREADS * 8)
 	{
-		if ((int)threadIdx.x < off)
-			for (int k = 0; k < 4; ++k) acc[threadIdx.x][k] += acc[threadIdx.x + off][k];
-		__syncthreads();
+		ulonglong4 v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+		{
+			const uint32_t i = base + (uint32_t)k * SDFR_REDUCE_THREADS;
+			v[k] = i < n ? src[i] : make_ulonglong4(0ull, 0ull, 0ull, 0ull);
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+		{
+			s[0] += v[k].x;
+			s[1] += v[k].y;
+			s[2] += v[k].z;
+			s[3] += v[k].w;
+		}
 	}
-	if (threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] += acc[0][threadIdx.x];
+	for (int off = 32; off > 0; off >>= 1)
+		for (int k = 0; k < 4; ++k) s[k] += __shfl_down(s[k], off);
+	if ((threadIdx.x & 63) == 0)
+		for (int k = 0; k < 4; ++k) atomicAdd(&acc[k], s[k]);
+	__syncthreads();
+	if (threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = acc[threadIdx.x];
 }
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_reduce_totals, dim3(1), dim3(SDFR_BLOCK), 0, stream, partials, n_blocks, totals);
+	hipLaunchKernelGGL(k_reduce_totals, dim3(1), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals);
 	return hipGetLastError();
 }
 

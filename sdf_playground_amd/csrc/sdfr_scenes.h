@@ -185,20 +185,6 @@ struct SceneLabyrinth
 		return t;
 	}
 
-	struct Objects { float wall, vase, wood, fire; vec3 torch_pos; };
-	static SDF_HD Objects eval_objects(vec3 p)
-	{
-		Objects o;
-		const vec3 wp = fold(p);
-		o.wall = walls(wp);
-		o.vase = vase(vase_local(wp));
-		const Torch t = torch(wp);
-		o.wood = t.wood;
-		o.fire = t.fire;
-		o.torch_pos = t.torch_pos;
-		return o;
-	}
-
 	// Bounding-ball culling of the two small, expensive objects.  The scene distance is a
 	// min() over objects, so an object whose distance is provably >= the running minimum can
 	// be left out without changing a single bit.  Bounds (checked numerically by
@@ -230,28 +216,36 @@ struct SceneLabyrinth
 		}
 		return d;
 	}
+	// The first object whose surface the point lies on names the material (MATERIAL macro chain,
+	// sdf_scene_labyrinth.hlsl:64-98).  Objects are evaluated only as far down the chain as needed,
+	// and the vase / torch only where their bounding balls (see dist) allow |distance| < 1e-4.
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
 		ground_material(sp, m);
-		Objects o = eval_objects(sp.pos);
-		if (on_surface(o.wall))
+		const vec3 wp = fold(sp.pos);
+		if (on_surface(walls(wp)))
 		{
 			m.mpos = sp.pos;
 			m.id = MAT_MARBLE_LIGHT;
+			return;
 		}
-		else if (on_surface(o.vase))
+		const vec3 q = vase_local(wp);
+		if (!beyond(q - V3(0.f, 1.2f, 0.f), SDFR_DIST_EPS, 1.35f + 0.15f + 0.01f) && on_surface(vase(q)))
 		{
 			m.mpos = sp.pos * 3.f;
 			m.id = MAT_MARBLE_DARK;
+			return;
 		}
-		else if (on_surface(o.wood))
+		if (beyond(wp - V3(5.f, 2.f, 3.f) - V3(0.2f, 0.9f, 0.f), SDFR_DIST_EPS, 0.9f + 0.01f)) return;
+		const Torch t = torch(wp);
+		if (on_surface(t.wood))
 		{
 			m.mpos = V3(sp.pos.x, sp.pos.z, sp.pos.y) * 2.f;
 			m.id = MAT_WOOD;
 		}
-		else if (on_surface(o.fire))
+		else if (on_surface(t.fire))
 		{
-			m.mpos = o.torch_pos * 3.f - V3(0.f, U.su[SU_FIRE_SCROLL], 0.f);
+			m.mpos = t.torch_pos * 3.f - V3(0.f, U.su[SU_FIRE_SCROLL], 0.f);
 			m.id = MAT_FIRE;
 		}
 	}
