@@ -12,6 +12,16 @@ namespace sdfr {
 
 #define SDFR_BLOCK 256
 #define SDFR_INVALID_PIXEL 0xffffffffu
+// Launch attributes of every pixel kernel.  The register allocator is held to 5 waves per SIMD
+// (<= 102 VGPRs): the VALU of gfx950 issues one instruction per wave every ~8 cycles
+// (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD, 2.5-3.3 at 8), so issue-bound code
+// wants residency more than it wants registers.  The spills this causes land in the shading
+// code; the march loop stays spill-free (checked in the ISA).  Measured at 4K: labyrinth
+// 1.77 -> 1.66 ms, cube_sea 7.1 -> 6.4, fractal 2.4 -> 2.15, tree 34.8 -> 30.5.
+#ifndef SDFR_PIXEL_WAVES_PER_EU
+#define SDFR_PIXEL_WAVES_PER_EU 5
+#endif
+#define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
 
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
