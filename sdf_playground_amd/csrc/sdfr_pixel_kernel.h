@@ -12,14 +12,16 @@ namespace sdfr {
 
 #define SDFR_BLOCK 256
 #define SDFR_INVALID_PIXEL 0xffffffffu
-// Launch attributes of every pixel kernel.  The register allocator is held to 5 waves per SIMD
-// (<= 102 VGPRs): the VALU of gfx950 issues one instruction per wave every ~8 cycles
-// (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD, 2.5-3.3 at 8), so issue-bound code
-// wants residency more than it wants registers.  The spills this causes land in the shading
-// code; the march loop stays spill-free (checked in the ISA).  Measured at 4K: labyrinth
-// 1.77 -> 1.66 ms, cube_sea 7.1 -> 6.4, fractal 2.4 -> 2.15, tree 34.8 -> 30.5.
+// Launch attributes of every pixel kernel.  The register allocator is held to 4 waves per SIMD
+// (<= 128 VGPRs; left alone it takes ~160 and fits 3): the VALU of gfx950 issues one instruction
+// per wave every ~8 cycles (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD, 2.5-3.3 at
+// 8), so issue-bound code wants residency more than registers.  With the ray cache and the pixel
+// footprint in LDS (LdsCachedRayStore) most scenes fit 128 without spilling (labyrinth: 21 spilled
+// dwords, all in the texture code; the march loop is spill-free).  5 waves (<= 96 VGPRs) is no
+// faster and its spills reach HBM (measured 1.36 GB per 4K labyrinth frame against 0.23 GB).
+// Measured at 4K, 3 -> 4 waves: labyrinth 1.77 -> 1.65 ms, cube_sea 7.1 -> 6.6, tree 34.8 -> 31.
 #ifndef SDFR_PIXEL_WAVES_PER_EU
-#define SDFR_PIXEL_WAVES_PER_EU 5
+#define SDFR_PIXEL_WAVES_PER_EU 4
 #endif
 #define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
 
@@ -151,12 +153,78 @@ struct GlobalRayStore
 	__device__ __forceinline__ RayRec get(int slot) const { return load_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid); }
 };
 
+// The pixel kernel's ray store: the write-behind cache of CachedRayStore and the pixel's ray
+// footprint, held in LDS instead of registers ([field][thread]: conflict-free).  Both live across
+// the whole bounce loop but are touched only around shading; as registers they cost 21 VGPRs at
+// the march loop, i.e. residency (see SDFR_PIXEL_WAVES_PER_EU) or scratch spills that reach HBM.
+enum { SDFR_LDS_RAY_FIELDS = 11, SDFR_LDS_PIXEL_RAY_FIELDS = 9 };
+// pointer that stays in the LDS address space (a plain float* would decay to a 64-bit flat
+// pointer: flat loads/stores and a register pair per precomputed field address)
+typedef __attribute__((address_space(3))) float lds_float;
+struct LdsCachedRayStore
+{
+	GlobalRayStore &backing;
+	lds_float *lds; // this thread's column of the block's [20][SDFR_BLOCK] array
+	int cached_slot;
+	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column) : backing(b), lds((lds_float *)column), cached_slot(-1) {}
+	__device__ __forceinline__ void write_rec(const RayRec &r)
+	{
+		lds[0 * SDFR_BLOCK] = r.pos.x; lds[1 * SDFR_BLOCK] = r.pos.y; lds[2 * SDFR_BLOCK] = r.pos.z;
+		lds[3 * SDFR_BLOCK] = r.dir.x; lds[4 * SDFR_BLOCK] = r.dir.y; lds[5 * SDFR_BLOCK] = r.dir.z;
+		lds[6 * SDFR_BLOCK] = r.contrib.x; lds[7 * SDFR_BLOCK] = r.contrib.y; lds[8 * SDFR_BLOCK] = r.contrib.z;
+		lds[9 * SDFR_BLOCK] = r.shadow_range;
+		lds[10 * SDFR_BLOCK] = __uint_as_float(r.bits);
+	}
+	__device__ __forceinline__ RayRec read_rec() const
+	{
+		RayRec r;
+		r.pos = V3(lds[0 * SDFR_BLOCK], lds[1 * SDFR_BLOCK], lds[2 * SDFR_BLOCK]);
+		r.dir = V3(lds[3 * SDFR_BLOCK], lds[4 * SDFR_BLOCK], lds[5 * SDFR_BLOCK]);
+		r.contrib = V3(lds[6 * SDFR_BLOCK], lds[7 * SDFR_BLOCK], lds[8 * SDFR_BLOCK]);
+		r.shadow_range = lds[9 * SDFR_BLOCK];
+		r.bits = __float_as_uint(lds[10 * SDFR_BLOCK]);
+		return r;
+	}
+	__device__ __forceinline__ void put(int i, const RayRec &r)
+	{
+		if (cached_slot >= 0) backing.put(cached_slot, read_rec());
+		write_rec(r);
+		cached_slot = i;
+	}
+	__device__ __forceinline__ RayRec get(int i)
+	{
+		if (i == cached_slot)
+		{
+			cached_slot = -1;
+			return read_rec();
+		}
+		return backing.get(i);
+	}
+	__device__ __forceinline__ void keep_pixel_ray(const PixelRay &pr)
+	{
+		lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
+		p[0 * SDFR_BLOCK] = pr.dir.x; p[1 * SDFR_BLOCK] = pr.dir.y; p[2 * SDFR_BLOCK] = pr.dir.z;
+		p[3 * SDFR_BLOCK] = pr.right_ray.x; p[4 * SDFR_BLOCK] = pr.right_ray.y; p[5 * SDFR_BLOCK] = pr.right_ray.z;
+		p[6 * SDFR_BLOCK] = pr.bottom_ray.x; p[7 * SDFR_BLOCK] = pr.bottom_ray.y; p[8 * SDFR_BLOCK] = pr.bottom_ray.z;
+	}
+	__device__ __forceinline__ PixelRay pixel_ray_kept() const
+	{
+		const lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
+		PixelRay pr;
+		pr.dir = V3(p[0 * SDFR_BLOCK], p[1 * SDFR_BLOCK], p[2 * SDFR_BLOCK]);
+		pr.right_ray = V3(p[3 * SDFR_BLOCK], p[4 * SDFR_BLOCK], p[5 * SDFR_BLOCK]);
+		pr.bottom_ray = V3(p[6 * SDFR_BLOCK], p[7 * SDFR_BLOCK], p[8 * SDFR_BLOCK]);
+		return pr;
+	}
+};
+
 // body of the pixel kernel; the __global__ wrappers are k_pixel (scenes compiled ahead of time,
 // sdfr_kernels.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
 template <class Scene, bool DBG>
 __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *partials, float *ray_queue, size_t cap)
 {
+	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_BLOCK];
 	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
 	PixelCounters c = {};
 	uint32_t npix = 0;
@@ -164,8 +232,8 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	if (w < n_work && work_to_pixel(U, rm, w, pc))
 	{
 		GlobalRayStore backing = {ray_queue, cap, pc.pid};
-		CachedRayStore<GlobalRayStore> store(backing);
-		vec4 v = render_pixel<Scene, DBG, CachedRayStore<GlobalRayStore>>(U, pc.px, pc.py, c, store);
+		LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
+		vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, c, store);
 		store_pixel(out, format, pc.pid, v);
 		if (pixel_stats)
 		{

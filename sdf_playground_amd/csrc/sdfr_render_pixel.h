@@ -21,13 +21,19 @@ struct LocalRayStore
 // in registers and reaches the backing store only when another push follows.  Most pixels
 // spawn a single child (the shadow ray) that is popped right away, so its 44-byte record never
 // travels to HBM and back.
+//
+// A store also keeps the pixel's ray footprint (PixelRay) between the prologue and the hit
+// shading that needs it for the checker filter: keep_pixel_ray / pixel_ray_kept.
 template <class Backing>
 struct CachedRayStore
 {
 	Backing &backing;
 	RayRec cached;
 	int cached_slot;
+	PixelRay kept;
 	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
+	SDF_HD void keep_pixel_ray(const PixelRay &pr) { kept = pr; }
+	SDF_HD PixelRay pixel_ray_kept() const { return kept; }
 	SDF_HD void put(int i, const RayRec &r)
 	{
 		if (cached_slot >= 0) backing.put(cached_slot, cached);
@@ -69,8 +75,12 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 {
 	SDFR_CLK(c_begin);
 	const DebugFlags F = debug_flags(U);
-	const PixelRay pr = pixel_ray(U, px, py);
-	RayRec ray = primary_ray(U, pr);
+	RayRec ray;
+	{
+		const PixelRay pr = pixel_ray(U, px, py);
+		ray = primary_ray(U, pr);
+		store.keep_pixel_ray(pr);
+	}
 	uint64_t depths = SDFR_QUEUE_EMPTY;
 	int count = 0; // rays waiting in the store
 
@@ -126,7 +136,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			SDFR_CLK_ADD(clk_grad, c1, c2);
 
 			Spawner<Store> q(store, depths, count, U.ray_count);
-			out = shade_hit<Scene, DBG, Store>(U, F, ray, pr, hit, max_range, hdr, q);
+			out = shade_hit<Scene, DBG, Store>(U, F, ray, store.pixel_ray_kept(), hit, max_range, hdr, q);
 			depths = q.depths;
 			count = q.count;
 #ifdef SDFR_PHASE_CLOCKS
