@@ -2,6 +2,9 @@
 
 Flags that matter for correctness:
   -ffp-contract=off   only the explicit fma() calls fuse (arithmetic contract)
+  -fno-slp-vectorize  no v_pk_*_f32: on gfx950 a packed fp32 op costs more issue time than the two
+                      scalar ops it replaces (tools/ubench: pk_add 6.1 vs 2 x 2.5 cycles); measured at
+                      4K: labyrinth -4 %, cube_sea -15 %, lense +5 %
   default hipcc fp32 divide/sqrt are correctly rounded and denormals are kept; do not add
   -ffast-math / -fgpu-flush-denormals-to-zero / -fno-hip-fp32-correctly-rounded-divide-sqrt.
 """
@@ -29,7 +32,7 @@ def build(force=False, verbose=False, extra=(), out=None):
     if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-x", "hip",
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-x", "hip",
            "-Wno-unused-result", "-Wno-unknown-pragmas", "-I" + CSRC] + list(extra)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or LIB]
     if verbose:

@@ -126,7 +126,7 @@ bool jit_compile_code(const std::string &arch_name, const std::string &name, con
 	// same code generation rules as the ahead-of-time build (buildlib.py): only explicit fma() fuses
 	const std::string arch = "--offload-arch=" + arch_name;
 	const std::string inc = "-I" + header_dir();
-	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", inc.c_str()};
+	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", inc.c_str()};
 	rc = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
 	size_t log_bytes = 0;
 	rtc.log_size(prog, &log_bytes);
