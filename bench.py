@@ -121,14 +121,22 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--force-distributed", action="store_true", help="take the strips + gather path even with one rank (testing)")
+    ap.add_argument("--verify", action="store_true", help="after timing, check rank 0's assembled image of the last frame against a direct render")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or a.force_distributed
+    saved_stdout = None
     if distributed:
         import torch.distributed as dist
+
+        # RCCL prints a version banner on stdout when the first communicator is made; the contract
+        # is ONE line on stdout, so stdout points at stderr until the result line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -148,7 +156,16 @@ def main():
     r.setStream(stream.cuda_stream)
 
     if distributed:
-        # double-buffered so that the gather + assembly of frame k overlap the render of frame k+1
+        # Two frames in flight.  Frames alternate between two renderer handles on two streams, so
+        # the tail of frame k (a handful of waves still marching 256-step rays: one wave alone needs
+        # ~0.2 ms, as long as a rank's whole share of the frame at 8 GPUs) overlaps the head of frame
+        # k+1; gather + assembly of frame k overlap the render of frame k+1 as well.
+        rs = [stream, torch.cuda.Stream()]
+        rr = [r, sp.SDFRenderer(local_rank)]
+        rr[1].initShader(SCENE)
+        rr[1].setLimits(iter_count=ITER_COUNT)
+        rr[1].setSchedule(schedule)
+        rr[1].setStream(rs[1].cuda_stream)
         n_local = sp.strip_buffer_pixels(W, H, world)
         local = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered_flat = [torch.empty((world, n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else None
@@ -161,27 +178,33 @@ def main():
     image = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 
     def step(s):
+        """Enqueue frame s; returns the handle that renders it."""
         cam, stime = make_camera(s % SWEEP, W, H)
-        r.setParameters(stime)
-        r.setCamera(cam)
         if not distributed:
+            r.setParameters(stime)
+            r.setCamera(cam)
             r.render(None, W, H, out=image)
-            return
+            return r
         b = s & 1
-        if works[b] is not None:
-            works[b].wait()                     # render stream: local[b] is free once gather s-2 is done
-        if rank == 0 and asm_done[b] is not None:
-            stream.wait_event(asm_done[b])      # gathered_flat[b] is free once assembly s-2 is done
-        r.renderStrips(W, H, rank, world, local[b])
-        if rank == 0:
-            works[b] = dist.gather(local[b], gather_list=list(gathered_flat[b].unbind(0)), dst=0, async_op=True)
-            with torch.cuda.stream(side):
-                works[b].wait()
-                r_asm.assembleStrips(W, H, world, gathered_flat[b], image)
-                asm_done[b] = torch.cuda.Event()
-                asm_done[b].record(side)
-        else:
-            works[b] = dist.gather(local[b], dst=0, async_op=True)
+        h = rr[b]
+        h.setParameters(stime)
+        h.setCamera(cam)
+        with torch.cuda.stream(rs[b]):
+            if works[b] is not None:
+                works[b].wait()                    # this frame's stream: local[b] is free once gather s-2 is done
+            if rank == 0 and asm_done[b] is not None:
+                rs[b].wait_event(asm_done[b])      # gathered_flat[b] is free once assembly s-2 is done
+            h.renderStrips(W, H, rank, world, local[b])
+            if rank == 0:
+                works[b] = dist.gather(local[b], gather_list=list(gathered_flat[b].unbind(0)), dst=0, async_op=True)
+                with torch.cuda.stream(side):
+                    works[b].wait()
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], image)
+                    asm_done[b] = torch.cuda.Event()
+                    asm_done[b].record(side)
+            else:
+                works[b] = dist.gather(local[b], dst=0, async_op=True)
+        return h
 
     def fence():
         torch.cuda.synchronize()
@@ -196,9 +219,10 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for s in range(a.steps):
-        ev[s][0].record(stream)
+        es = rs[s & 1] if distributed else stream
+        ev[s][0].record(es)
         step(s)
-        ev[s][1].record(stream)
+        ev[s][1].record(es)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -206,8 +230,7 @@ def main():
     rays_per_frame = []
     kernel_ms = []
     for k in range(min(SWEEP, a.steps)):
-        step(k)
-        st = r.getStats()
+        st = step(k).getStats()
         rays_per_frame.append(int(st.rays))
         kernel_ms.append(st.ms_gpu)
     my_rays = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(a.steps))
@@ -220,6 +243,24 @@ def main():
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_rays = float(rays_t.item())
+
+    verified = None
+    if a.verify and rank == 0:
+        last = a.steps - 1
+        step(last)
+        fence_local = torch.cuda.synchronize
+        fence_local()
+        got = image.clone()
+        cam, stime = make_camera(last % SWEEP, W, H)
+        r.setParameters(stime)
+        r.setCamera(cam)
+        ref = torch.empty_like(got)
+        r.render(None, W, H, out=ref)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(got.view(torch.int32), ref.view(torch.int32)))
+    elif a.verify and distributed:
+        step(a.steps - 1)  # every rank takes part in the extra gather
+        torch.cuda.synchronize()
 
     if rank == 0:
         census = load_census()
@@ -244,21 +285,33 @@ def main():
             },
         }
         # roofline of the dominant kernel (the only kernel of the pixel schedule), N = 1 geometry
-        mean_kernel_ms = float(np.mean(kernel_ms))
+        # kernel duration: HIP events on the launch stream.  N = 1: the pairs recorded around every
+        # step of the timed region (a step launches k_pixel + the 12-us counter fold and nothing
+        # else); N > 1: a step also gathers, so the handle's own events of the counting pass are used
+        stats_pass_ms = float(np.mean(kernel_ms))
+        mean_kernel_ms = stats_pass_ms if distributed else float(np.mean(step_ms))
         mean_rays = float(np.mean(rays_per_frame))
         if census:
             flops_per_launch = census["flops_per_ray"] * mean_rays
             achieved = flops_per_launch / (mean_kernel_ms * 1e-3) / 1e12
             traffic = None
+            pmc = None
             try:
                 with open(PMC_FILE) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+                    pj = json.load(fh)
+                traffic = pj.get("hbm_bytes_per_launch")
+                for name, k in pj.get("kernels", {}).items():
+                    if "k_pixel" in name:
+                        # executed work (rocprofv3 --pmc over this same command, profiles/pmc_r01.json): the
+                        # census numerator above is algorithmic and includes evaluations the kernel culls
+                        pmc = {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "valu_lane_utilization": k["valu_lane_utilization"],
+                               "cycles_per_valu_instruction_per_simd": k["cycles_per_valu_inst_per_simd"], "waves_per_simd": k["avg_waves_per_simd"]}
             except Exception:
                 pass
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic,
-                "kernel_ms": mean_kernel_ms, "flops_per_ray": census["flops_per_ray"],
+                "kernel_ms": mean_kernel_ms, "kernel_ms_counting_pass": stats_pass_ms, "flops_per_ray": census["flops_per_ray"], "pmc": pmc,
                 "note": "FP32 vector (VALU) issue bounds this path, not HBM or MFMA (SURVEY.md 8d); flops = oracle operation census",
             }
         bytes_per_launch = 16.0 * W * H / world
@@ -268,11 +321,16 @@ def main():
             "note": "algorithmic bytes = one 16-byte RGBA32F store per pixel; reported because the north star asks for it",
         }
         out["step_ms_event_median"] = float(np.median(step_ms))
+        if verified is not None:
+            out["verified"] = verified
         if not distributed and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the bench line must still be printed
                 out["cpu_baseline"] = {"error": repr(e)}
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
 
     r.close()
