@@ -19,8 +19,27 @@
 
 namespace sdfr {
 
-__constant__ float k_bloom_coeffs[17] = {0.070771f, 0.069674f, 0.066483f, 0.061487f, 0.055116f, 0.047886f, 0.040324f, 0.032912f, 0.026035f,
-	0.019962f, 0.014834f, 0.010685f, 0.007459f, 0.005047f, 0.003310f, 0.002104f, 0.001296f};
+// bloom.hlsl:3-12
+constexpr float bloom_coeff(int i)
+{
+	constexpr float c[17] = {0.070771f, 0.069674f, 0.066483f, 0.061487f, 0.055116f, 0.047886f, 0.040324f, 0.032912f, 0.026035f,
+		0.019962f, 0.014834f, 0.010685f, 0.007459f, 0.005047f, 0.003310f, 0.002104f, 0.001296f};
+	return c[i < 0 ? -i : i];
+}
+// The 33 taps are unrolled by template recursion: the weights are constant expressions and
+// become literals of the multiplies (an SGPR or constant-memory operand halves the VALU issue
+// rate).  STRIDE = distance in float4 elements between two taps of the staged tile.
+template <int I, int STRIDE>
+struct Taps
+{
+	static __device__ __forceinline__ void run(vec4 &sum, const float4 *centre)
+	{
+		constexpr float w = bloom_coeff(I);
+		const float4 t = centre[I * STRIDE];
+		sum = sum + V4(t.x, t.y, t.z, t.w) * w;
+		if constexpr (I < 16) Taps<I + 1, STRIDE>::run(sum, centre);
+	}
+};
 
 __device__ __forceinline__ vec4 load_half4(const uint2 *img, size_t idx)
 {
@@ -73,12 +92,7 @@ __global__ __launch_bounds__(256) void k_bloom_h(const uint2 *__restrict__ scene
 	const int x = x0 + threadIdx.x;
 	if (x >= width) return;
 	vec4 sum = V4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-	for (int i = -16; i <= 16; ++i)
-	{
-		const float4 t = tile[threadIdx.x + POST_HALO + 2 * i];
-		sum = sum + V4(t.x, t.y, t.z, t.w) * k_bloom_coeffs[i < 0 ? -i : i];
-	}
+	Taps<-16, 2>::run(sum, &tile[threadIdx.x + POST_HALO]);
 	bloom1[(size_t)y * width + x] = pack_half4(sum * 2.f);
 }
 
@@ -109,12 +123,7 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 		const int y = y0 + r;
 		if (y >= height) break;
 		vec4 sum = V4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-		for (int i = -16; i <= 16; ++i)
-		{
-			const float4 t = tile[r + POST_HALO + 2 * i][tx];
-			sum = sum + V4(t.x, t.y, t.z, t.w) * k_bloom_coeffs[i < 0 ? -i : i];
-		}
+		Taps<-16, 2 * POST_TX>::run(sum, &tile[r + POST_HALO][tx]);
 		const vec4 bloom = through_half4(sum * 2.f); // the reference stores bloom2 as f16
 		const vec4 sc = load_half4(scene, (size_t)y * width + x);
 		const vec4 total = sc + bloom;
