@@ -70,25 +70,29 @@ struct SceneTree
 		const vec2 local = (uv - cell) - 0.5f;
 		float best = 10.f, edge = 10.f;
 		vec2 best_site = V2(0.f, 0.f);
+		// the reference hashes the nine neighbour sites twice (once per loop); same inputs, same
+		// values: they are kept from the first pass
+		vec2 sites[9];
+#pragma unroll
 		for (int x = -1; x < 2; ++x)
+#pragma unroll
 			for (int y = -1; y < 2; ++y)
 			{
 				const vec2 off = V2((float)x, (float)y);
 				const vec2 site = off + voronoi_site(cell + off) * max_offset;
+				sites[(x + 1) * 3 + (y + 1)] = site;
 				const vec2 v = site - local;
 				const float len = length(v);
 				if (len < best) { best = len; *id = cell + off; best_site = site; *to_site = v; }
 			}
-		for (int x = -1; x < 2; ++x)
-			for (int y = -1; y < 2; ++y)
-			{
-				const vec2 off = V2((float)x, (float)y);
-				const vec2 site = off + voronoi_site(cell + off) * max_offset;
-				const vec2 mid = (site + best_site) * 0.5f;
-				const vec2 n = normalize(best_site - mid);
-				const float e = abs1(dot(n, local - mid));
-				edge = min1(edge, e / max1(dot(n, -dir), 0.0001f));
-			}
+#pragma unroll
+		for (int k = 0; k < 9; ++k)
+		{
+			const vec2 mid = (sites[k] + best_site) * 0.5f;
+			const vec2 n = normalize(best_site - mid);
+			const float e = abs1(dot(n, local - mid));
+			edge = min1(edge, e / max1(dot(n, -dir), 0.0001f));
+		}
 		*border = edge;
 	}
 	// slide for `slide_time`, then hop for `jump_time`: (progress along the slide, hop height)
