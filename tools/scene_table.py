@@ -1,0 +1,39 @@
+"""Developer timing table: every built-in scene at 3840x2160, iter_count 256, pixel schedule
+(median of 3 frames after a warm-up), plus the host-destination (PCIe-inclusive) labyrinth rate."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import torch
+import sdf_playground_amd as sp
+from quickbench import camera_for
+
+W, H = 3840, 2160
+r = sp.SDFRenderer(0)
+out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+print("scene                 ms/frame   Mrays/s  rays/px  evals/ray")
+for scene in sp.scene_names():
+    r.initShader(scene)
+    r.setLimits(iter_count=256)
+    ms, st = [], None
+    for k in range(4):
+        r.setParameters(k / 60.0)
+        r.render(camera_for(scene, k, W, H), W, H, out=out)
+        st = r.getStats()
+        if k:
+            ms.append(st.ms_gpu)
+    m = float(np.median(ms))
+    print("%-20s %9.3f %9.1f %8.2f %10.1f" % (scene, m, st.rays / m / 1e3, st.rays / st.pixels, st.march_evals / max(1, st.rays)), flush=True)
+r.initShader("labyrinth")
+r.setLimits(iter_count=256)
+cam = camera_for("labyrinth", 1, W, H)
+r.render(cam, W, H)
+t0 = time.perf_counter()
+for _ in range(5):
+    img = r.render(cam, W, H)  # numpy result: kernel + 132.7 MB device-to-host copy
+dt = (time.perf_counter() - t0) / 5
+print("labyrinth to a host buffer (PCIe-inclusive): %.2f ms/frame, %.0f Mrays/s" % (dt * 1e3, r.getStats().rays / dt / 1e6))
+r.close()
