@@ -343,13 +343,19 @@ class SDFRenderer:
     def render(self, camera=None, width=1200, height=800, out=None, fmt=RGBA32F, pixel_stats=False):
         """Renders one frame.  `out` may be a CUDA/HIP torch tensor ([H,W,4] float32 or
         float16) -> device-to-device, asynchronous on the renderer's stream; otherwise a host
-        numpy array is returned (synchronous).  With pixel_stats=True also returns
-        [H,W,3] uint32 {rays, march evaluations, hits} (host path only)."""
+        numpy array is returned (synchronous).  pixel_stats: True (host path) also returns
+        [H,W,3] uint32 {rays, march evaluations, hits}; with a device `out` it may be a device
+        int32/uint32 tensor [H,W,3] that receives them."""
         if camera is not None:
             self.setCamera(camera)
         if out is not None and hasattr(out, "data_ptr"):
             assert out.is_cuda and out.is_contiguous() and out.numel() == width * height * 4
-            self._check(self._L.sdfr_render(self._h, width, height, ctypes.c_void_p(out.data_ptr()), fmt, 0, None))
+            pst = None
+            if pixel_stats is not False and pixel_stats is not None:
+                assert hasattr(pixel_stats, "data_ptr") and pixel_stats.is_cuda and pixel_stats.is_contiguous()
+                assert pixel_stats.numel() == width * height * 3 and pixel_stats.element_size() == 4
+                pst = ctypes.c_void_p(pixel_stats.data_ptr())
+            self._check(self._L.sdfr_render(self._h, width, height, ctypes.c_void_p(out.data_ptr()), fmt, 0, pst))
             return out
         dt = np.float32 if fmt == RGBA32F else np.float16
         img = np.zeros((height, width, 4), dt) if out is None else out

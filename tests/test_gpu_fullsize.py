@@ -1,0 +1,93 @@
+"""GPU tier: the BASELINE.json configurations at their FULL sizes.
+
+The oracle cannot render 8.3 Mpixel frames in test time, but it can render any subset of pixels
+of such a frame: every config is rendered at full size on the GPU and compared bit for bit with
+the oracle on a regular sample of its pixels (pixels are independent, so a sample is as good as
+any other), plus the size-independent properties the domain offers: a second render is
+bit-identical (idempotence), the 8-way strip decomposition reassembles to the same frame, and
+the frame's ray total equals the sum of the per-pixel counters."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pcg(x):
+    state = (x * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+def _theta(seed, k):
+    return 2.0 * math.pi * (k + _pcg((seed + k) & 0xFFFFFFFF) / 4294967295.0) / 16
+
+
+# (scene, W, H, limits, camera of sweep frame k = 5, stime) as concretised in SURVEY.md 8d
+def _configs():
+    k = 5
+    t2, t3, t4, t5 = (_theta(s, k) for s in (0x5DF00002, 0x5DF00003, 0x5DF00004, 0x5DF00005))
+    ph = -0.5 + (k + _pcg((0x5DF00005 + k) & 0xFFFFFFFF) / 4294967295.0) / 16
+    return [
+        ("cube_sea", 1920, 1080, dict(iter_count=128, max_cost_default=6), ("dir", (3 * math.cos(t2), 4.5, 3 * math.sin(t2)),
+                                                                            (math.cos(t2 + 0.6), -0.45, math.sin(t2 + 0.6))), k / 60.0, 8),
+        ("labyrinth", 3840, 2160, dict(iter_count=256), ("dir", (1.5 * math.cos(t3), 5.0, 1.5 * math.sin(t3)), (math.cos(t3), -0.35, math.sin(t3))), k / 60.0, 16),
+        ("fractal", 3840, 2160, dict(iter_count=512), ("lookat", (2.2 * math.cos(t4), 1.6, 2.2 * math.sin(t4)), (0, 1, 0)), 0.0, 16),
+        ("lense", 3840, 2160, dict(iter_count=100, max_cost_default=9), ("lookat", (7 * math.sin(ph), 0.5, 7 * math.cos(ph)), (0, 0, 0)), k / 60.0, 16),
+        ("gems", 3840, 2160, dict(iter_count=100, max_cost_default=9), ("lookat", (2.5 * math.cos(t5), 2, 2.5 * math.sin(t5)), (0, 1, 0)), k / 60.0, 16),
+    ]
+
+
+@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c[0])
+def test_full_size_config_matches_oracle_on_a_pixel_sample(oracle, cfg):
+    import sdf_playground_amd as sp
+    import torch
+
+    scene, W, H, limits, (kind, eye, tgt), stime, stride = cfg
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    asp = np.float32(W) / np.float32(H)
+    basis = (oracle.camera_lookat if kind == "lookat" else oracle.camera_direction)(eye, tgt, fovy, asp)
+    f = oracle.default_frame(scene, W, H, basis=basis, stime=stime)
+    for name, v in limits.items():
+        setattr(f, name, v)
+
+    r = sp.SDFRenderer(0)
+    r.initShader(scene)
+    r.setParameters(stime)
+    r.setLimits(**limits)
+    cam = sp.Camera()
+    cam.SetEye(eye)
+    (cam.SetLookat if kind == "lookat" else cam.SetDirection)(tgt)
+    cam.SetFOVY(float(fovy))
+    cam.SetAspect(float(asp))
+    r.setCamera(cam)
+
+    img = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    pst = torch.empty((H, W, 3), dtype=torch.int32, device="cuda")
+    r.render(None, W, H, out=img, pixel_stats=pst)
+    s = r.getStats()
+    assert s.pixels == W * H
+    assert int(pst[..., 0].sum(dtype=torch.int64)) == s.rays and int(pst[..., 1].sum(dtype=torch.int64)) == s.march_evals
+
+    # the oracle on every stride-th pixel
+    ref, rst, _ = oracle.render(scene, f, step=(stride, stride), stats=True)
+    got = img[::stride, ::stride].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref[::stride, ::stride].view(np.uint32)), scene
+    assert np.array_equal(pst[::stride, ::stride].cpu().numpy().view(np.uint32), rst[::stride, ::stride])
+
+    # idempotence
+    img2 = torch.empty_like(img)
+    r.render(None, W, H, out=img2)
+    assert torch.equal(img.view(torch.int32), img2.view(torch.int32))
+
+    # 8-way strips reassemble to the same frame
+    world = 8
+    n = sp.strip_buffer_pixels(W, H, world)
+    gathered = torch.empty((world, n, 4), dtype=torch.float32, device="cuda")
+    for rank in range(world):
+        r.renderStrips(W, H, rank, world, out=gathered[rank])
+    r.assembleStrips(W, H, world, gathered, img2)
+    r.sync()
+    assert torch.equal(img.view(torch.int32), img2.view(torch.int32))
+    r.close()
