@@ -100,6 +100,10 @@ typedef struct sdfr_limits
 	int light_count;      /* LIGHT_COUNT  8, 0..8 */
 	float range;          /* RANGE        100 */
 	int max_cost_default; /* MaterialOutput.max_cost 7, 0..250 */
+	/* EXTENSION, 0 = reference: n = 1..7 point lights orbiting at radius 5, height 3 overwrite slots
+	 * 1..n of the scene's map_light table (the "8 lights" variant of the lense/gems benchmark
+	 * configuration; the reference's scenes carry one light).  DESIGN.md section 2. */
+	int extension_lights;
 } sdfr_limits;
 int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out);
 int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *limits);

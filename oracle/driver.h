@@ -50,6 +50,27 @@ inline float3 get_debug_plane_normal(const Frame &F)
 inline bool debug_show_objects(const Frame &F) { return any(F.show_objects); }
 
 // :111-135
+// EXTENSION, not in the reference (SURVEY.md 8d cfg 5: "8 lights"): slots 1..n of the light table
+// are overwritten with point lights orbiting at height 3, radius 5:
+//   phi_i = stime * 0.25 + i * (2 pi / 7), pos = (5 cos phi_i, 3, 5 sin phi_i), extend .25,
+//   falloff .25, colour = the hue wheel of scenes/sdf_scene_light_shadows.hlsl:5-11 at h = i / 7,
+//   normalised to unit brightness, times 0.5.
+inline void extension_lights(const Frame &F, LightOutput *output)
+{
+	for (int i = 1; i <= F.extension_lights && i < MAX_LIGHT_COUNT; ++i)
+	{
+		const real phi = F.stime * real(0.25f) + real((float)i) * real(6.28318530718f / 7.f);
+		const real h = real((float)i) / real(7.f);
+		float3 color = HSVtoRGB(float3(h, real(1.f), real(1.f)));
+		color = color / RGBtoBrightness(color);
+		output[i].used = true;
+		output[i].pos = float4(r_cos(phi) * real(5.f), real(3.f), r_sin(phi) * real(5.f), real(0.f));
+		output[i].extend = real(0.25f);
+		output[i].falloff = real(0.25f);
+		output[i].color = color * real(0.5f);
+	}
+}
+
 template <class Scene>
 inline real map_geometry(const Frame &F, const GeometryInput &geometry, const MarchingInput &march)
 {
@@ -466,6 +487,7 @@ inline float4 ps_main(const Frame &F, int px, int py, PixelStats &stats)
 
 					real ambient_lighting_factor = 0.075f;
 					Scene::map_light(F, geometry_input, light_output, ambient_lighting_factor);
+					extension_lights(F, light_output);
 
 					// :519-521
 					float3 view_dir = geometry_input.dir.xyz();

@@ -41,6 +41,7 @@ struct orc_frame
 	int max_cost_default;
 	float debug_nx, debug_ny, debug_nz, debug_scale, debug_x, debug_y, debug_z, show_objects;
 	float scene_var[8];
+	int extension_lights; // 0..7, extension (SURVEY.md 8d cfg 5)
 };
 
 } // extern "C"
@@ -148,6 +149,7 @@ Frame to_frame(const orc_frame &f)
 	F.show_objects = f.show_objects;
 	for (int i = 0; i < MAX_SCENE_VARS; ++i)
 		F.scene_var[i] = f.scene_var[i];
+	F.extension_lights = f.extension_lights < 0 ? 0 : (f.extension_lights > 7 ? 7 : f.extension_lights);
 	return F;
 }
 

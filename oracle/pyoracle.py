@@ -38,6 +38,7 @@ class OrcFrame(ctypes.Structure):
         ("debug_z", ctypes.c_float),
         ("show_objects", ctypes.c_float),
         ("scene_var", ctypes.c_float * 8),
+        ("extension_lights", ctypes.c_int),
     ]
 
 

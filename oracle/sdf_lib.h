@@ -50,6 +50,9 @@ struct Frame
 	real debug_nx, debug_ny, debug_nz, debug_scale, debug_x, debug_y, debug_z, show_objects;
 	// scene variables in the scene's declaration order
 	real scene_var[MAX_SCENE_VARS];
+	// EXTENSION (not in the reference; SURVEY.md 8d cfg 5 "8 lights"): number of orbiting point
+	// lights placed in slots 1..n after the scene's map_light; 0 = reference behaviour
+	int extension_lights;
 };
 
 // sdf_structs.hlsl:4-21

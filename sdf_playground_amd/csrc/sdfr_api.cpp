@@ -394,6 +394,7 @@ int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out)
 	out->light_count = r->U.light_count;
 	out->range = r->U.range;
 	out->max_cost_default = (int)r->U.max_cost_default;
+	out->extension_lights = r->U.extension_lights;
 	return SDFR_OK;
 }
 
@@ -402,7 +403,7 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 	if (!r || !l) return SDFR_ERR_INVALID_ARGUMENT;
 	if (l->iter_count < 1 || l->iter_count > 0xffffff || l->bounce_count < 0 || l->bounce_count > 16 || l->ray_count < 1 ||
 		l->ray_count > SDFR_MAX_RAYS || l->light_count < 0 || l->light_count > SDFR_MAX_LIGHTS || l->max_cost_default < 0 ||
-		l->max_cost_default > 250 || !(l->range == l->range))
+		l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1)
 		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
 	r->U.iter_count = l->iter_count;
 	r->U.bounce_count = l->bounce_count;
@@ -410,6 +411,7 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 	r->U.light_count = l->light_count;
 	r->U.range = l->range;
 	r->U.max_cost_default = (uint32_t)l->max_cost_default;
+	r->U.extension_lights = l->extension_lights;
 	return SDFR_OK;
 }
 

@@ -29,6 +29,11 @@ struct FrameU
 	float ddx, ddy;      // screen-space derivatives of the NDC coordinate: 2/W, -2/H
 	float sky_s, sky_c;  // sin/cos(-stime * 0.025) for the shared sky
 	float su[SDFR_SCENE_UNIFORMS]; // scene-specific constants (Scene::prepare)
+	// EXTENSION, not in the reference (SURVEY.md 8d cfg 5, "8 lights"): n orbiting point lights
+	// that overwrite slots 1..n of the scene's light table; position xyz + colour rgb, derived on
+	// the host per frame (sdfr_hostframe.h).  0 = reference behaviour.
+	int extension_lights;
+	float ext_light[SDFR_MAX_LIGHTS - 1][6];
 };
 
 // One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct

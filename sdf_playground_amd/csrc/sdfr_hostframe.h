@@ -33,6 +33,24 @@ inline void frame_derive(FrameU &U, int scene_index)
 	U.sky_c = sc.y;
 	for (int i = 0; i < SDFR_SCENE_UNIFORMS; ++i)
 		U.su[i] = 0.f;
+	// extension lights: phi_i = stime * 0.25 + i * (2 pi / 7); (5 cos phi, 3, 5 sin phi); the hue
+	// wheel of sdf_scene_light_shadows.hlsl:5-11 at h = i / 7, unit brightness, times 0.5
+	for (int i = 1; i < SDFR_MAX_LIGHTS; ++i)
+	{
+		float *L = U.ext_light[i - 1];
+		for (int k = 0; k < 6; ++k) L[k] = 0.f;
+		if (i > U.extension_lights) continue;
+		const float phi = U.stime * 0.25f + (float)i * (6.28318530718f / 7.f);
+		vec3 c = hsv_to_rgb(V3((float)i / 7.f, 1.f, 1.f));
+		c = c / rgb_to_brightness(c);
+		c = c * 0.5f;
+		L[0] = cos1(phi) * 5.f;
+		L[1] = 3.f;
+		L[2] = sin1(phi) * 5.f;
+		L[3] = c.x;
+		L[4] = c.y;
+		L[5] = c.z;
+	}
 	switch (scene_index)
 	{
 #define SDFR_PREP(I, S) case I: S::prepare(U); break;

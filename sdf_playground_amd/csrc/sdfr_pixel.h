@@ -403,7 +403,18 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 			for (int i = 0; i < U.light_count; ++i)
 			{
 				Light L;
-				if (!Scene::light(U, i, L)) continue;
+				bool used = Scene::light(U, i, L);
+				if (i >= 1 && i <= U.extension_lights) // extension: orbiting point lights (sdfr_frame.h)
+				{
+					const float *E = U.ext_light[i - 1];
+					L.pos = V3(E[0], E[1], E[2]);
+					L.directional = false;
+					L.extend = 0.25f;
+					L.falloff = 0.25f;
+					L.color = V3(E[3], E[4], E[5]);
+					used = true;
+				}
+				if (!used) continue;
 				vec3 ldir;
 				float trace_dist;
 				float falloff = 1.f;

@@ -12,16 +12,17 @@ namespace sdfr {
 
 #define SDFR_BLOCK 256
 #define SDFR_INVALID_PIXEL 0xffffffffu
-// Launch attributes of every pixel kernel.  The register allocator is held to 4 waves per SIMD
-// (<= 128 VGPRs; left alone it takes ~160 and fits 3): the VALU of gfx950 issues one instruction
-// per wave every ~8 cycles (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD, 2.5-3.3 at
-// 8), so issue-bound code wants residency more than registers.  With the ray cache and the pixel
-// footprint in LDS (LdsCachedRayStore) most scenes fit 128 without spilling (labyrinth: 21 spilled
-// dwords, all in the texture code; the march loop is spill-free).  5 waves (<= 96 VGPRs) is no
-// faster and its spills reach HBM (measured 1.36 GB per 4K labyrinth frame against 0.23 GB).
-// Measured at 4K, 3 -> 4 waves: labyrinth 1.77 -> 1.65 ms, cube_sea 7.1 -> 6.6, tree 34.8 -> 31.
+// Launch attributes of every pixel kernel.  The register allocator is held to 7 waves per SIMD
+// (<= 72 VGPRs; left alone it takes ~100-160 and fits 3-4): the VALU of gfx950 issues one
+// instruction per wave every ~8 cycles (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD,
+// 2.5-3.3 at 8), so issue-bound code wants residency more than registers.  With the ray cache and
+// the pixel footprint in LDS (LdsCachedRayStore) and without SLP vectorisation the march loops
+// need ~60 registers; at 72 a dozen dwords spill in the shading code (labyrinth: 12), none in a
+// march loop (checked in the ISA).  8 waves are out of reach: 8 blocks x 20.5 KB of LDS > 160 KB.
+// Measured at 4K (labyrinth / fractal / lense, ms): 3 waves 1.77 / 2.4 / 7.9 (allocator's choice),
+// 4: 1.61 / 2.2 / 7.9, 5: 1.55 / 2.16 / 7.8, 6: 1.50 / 2.25 / 8.0, 7: 1.43 / 2.03 / 7.2.
 #ifndef SDFR_PIXEL_WAVES_PER_EU
-#define SDFR_PIXEL_WAVES_PER_EU 4
+#define SDFR_PIXEL_WAVES_PER_EU 7
 #endif
 #define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
 

@@ -115,3 +115,18 @@ def test_fast_math_domain_is_respected_on_all_scenes(oracle):
         # comparison that follows -- and the GPU parity tests cover both scenes.
         if gu.scene_of(path) not in ("basic_clouds", "tree"):
             assert oracle.census.last_far_field == 0, path
+
+
+@pytest.mark.parametrize("scene", ["lense", "gems", "light_shadows"])
+def test_extension_lights_host_stages_match_oracle(oracle, scene):
+    """The "8 lights" extension (SURVEY.md 8d cfg 5): 7 orbiting point lights in slots 1..7."""
+    import hostsim
+
+    f = oracle.default_frame(scene, 96, 64, stime=0.8)
+    f.extension_lights = 7
+    ref, rst, tot = oracle.render(scene, f, stats=True)
+    base, _, tot0 = oracle.render(scene, oracle.default_frame(scene, 96, 64, stime=0.8), stats=True)
+    assert int(tot[1]) > int(tot0[1]) and not np.array_equal(ref, base)   # more shadow rays, another picture
+    img, st = hostsim.render(scene, hostsim.frame_from_oracle(f))
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(st, rst)

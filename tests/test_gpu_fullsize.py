@@ -34,8 +34,8 @@ def _configs():
                                                                             (math.cos(t2 + 0.6), -0.45, math.sin(t2 + 0.6))), k / 60.0, 8),
         ("labyrinth", 3840, 2160, dict(iter_count=256), ("dir", (1.5 * math.cos(t3), 5.0, 1.5 * math.sin(t3)), (math.cos(t3), -0.35, math.sin(t3))), k / 60.0, 16),
         ("fractal", 3840, 2160, dict(iter_count=512), ("lookat", (2.2 * math.cos(t4), 1.6, 2.2 * math.sin(t4)), (0, 1, 0)), 0.0, 16),
-        ("lense", 3840, 2160, dict(iter_count=100, max_cost_default=9), ("lookat", (7 * math.sin(ph), 0.5, 7 * math.cos(ph)), (0, 0, 0)), k / 60.0, 16),
-        ("gems", 3840, 2160, dict(iter_count=100, max_cost_default=9), ("lookat", (2.5 * math.cos(t5), 2, 2.5 * math.sin(t5)), (0, 1, 0)), k / 60.0, 16),
+        ("lense", 3840, 2160, dict(iter_count=100, max_cost_default=9, extension_lights=7), ("lookat", (7 * math.sin(ph), 0.5, 7 * math.cos(ph)), (0, 0, 0)), k / 60.0, 16),
+        ("gems", 3840, 2160, dict(iter_count=100, max_cost_default=9, extension_lights=7), ("lookat", (2.5 * math.cos(t5), 2, 2.5 * math.sin(t5)), (0, 1, 0)), k / 60.0, 16),
     ]
 
 

@@ -72,7 +72,7 @@ def _setup(renderer, oracle, scene, stime, limits=None, variables=None):
     renderer.setCamera(cam)
     # the C++ host camera must reproduce the oracle's (and the reference's) basis bit for bit
     assert np.array_equal(renderer.getCameraBasis().view(np.uint32), basis.view(np.uint32))
-    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7)
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0)
     if limits:
         renderer.setLimits(**limits)
         for k, v in limits.items():
@@ -123,6 +123,9 @@ def test_scene_parity_reference_limits(renderer, oracle, scene, stime, schedule)
     ("lense", dict(max_cost_default=9)),                         # config 5: recursion depth 4
     ("light_shadows", dict(ray_count=4, bounce_count=6)),       # queue overflow / bounce budget (Q4)
     ("gems", dict(light_count=0)),
+    ("lense", dict(max_cost_default=9, extension_lights=7)),    # config 5 as worded: depth 4, 8 lights (queue overflow, Q4)
+    ("gems", dict(max_cost_default=9, extension_lights=7)),
+    ("light_shadows", dict(extension_lights=3)),                # extension slots overwrite the scene's own lights 1..3
 ])
 def test_scene_parity_extension_limits(renderer, oracle, scene, limits):
     f = _setup(renderer, oracle, scene, 0.5, limits=limits)
@@ -184,7 +187,7 @@ def test_ragged_sizes(renderer, oracle, size):
     cam = sp.Camera()
     cam.SetAspect(float(np.float32(w) / np.float32(h)))
     renderer.setCamera(cam)
-    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7)
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0)
     f = oracle.default_frame("fast_sphere", w, h)
     ref, _, _ = oracle.render("fast_sphere", f)
     for schedule in (0, 1):
