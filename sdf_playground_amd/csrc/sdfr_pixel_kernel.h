@@ -18,9 +18,9 @@ namespace sdfr {
 // 2.5-3.3 at 8), so issue-bound code wants residency more than registers.  With the ray cache and
 // the pixel footprint in LDS (LdsCachedRayStore) and without SLP vectorisation the march loops
 // need ~60 registers; at 72 a dozen dwords spill in the shading code (labyrinth: 12), none in a
-// march loop (checked in the ISA).  8 waves are out of reach: 8 blocks x 20.5 KB of LDS > 160 KB.
+// march loop (checked in the ISA).  8 waves (64 VGPRs, 40 spilled dwords) are no faster.
 // Measured at 4K (labyrinth / fractal / lense, ms): 3 waves 1.77 / 2.4 / 7.9 (allocator's choice),
-// 4: 1.61 / 2.2 / 7.9, 5: 1.55 / 2.16 / 7.8, 6: 1.50 / 2.25 / 8.0, 7: 1.43 / 2.03 / 7.2.
+// 4: 1.61 / 2.2 / 7.9, 5: 1.55 / 2.16 / 7.8, 6: 1.50 / 2.25 / 8.0, 7: 1.43 / 2.03 / 7.2, 8: 1.5 / 2.1 / 7.2.
 #ifndef SDFR_PIXEL_WAVES_PER_EU
 #define SDFR_PIXEL_WAVES_PER_EU 7
 #endif
@@ -158,14 +158,14 @@ struct GlobalRayStore
 // footprint, held in LDS instead of registers ([field][thread]: conflict-free).  Both live across
 // the whole bounce loop but are touched only around shading; as registers they cost 21 VGPRs at
 // the march loop, i.e. residency (see SDFR_PIXEL_WAVES_PER_EU) or scratch spills that reach HBM.
-enum { SDFR_LDS_RAY_FIELDS = 11, SDFR_LDS_PIXEL_RAY_FIELDS = 9 };
+enum { SDFR_LDS_RAY_FIELDS = 11, SDFR_LDS_PIXEL_RAY_FIELDS = 6 }; // of the footprint only the two offset vectors are used again
 // pointer that stays in the LDS address space (a plain float* would decay to a 64-bit flat
 // pointer: flat loads/stores and a register pair per precomputed field address)
 typedef __attribute__((address_space(3))) float lds_float;
 struct LdsCachedRayStore
 {
 	GlobalRayStore &backing;
-	lds_float *lds; // this thread's column of the block's [20][SDFR_BLOCK] array
+	lds_float *lds; // this thread's column of the block's [17][SDFR_BLOCK] array
 	int cached_slot;
 	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column) : backing(b), lds((lds_float *)column), cached_slot(-1) {}
 	__device__ __forceinline__ void write_rec(const RayRec &r)
@@ -204,17 +204,16 @@ struct LdsCachedRayStore
 	__device__ __forceinline__ void keep_pixel_ray(const PixelRay &pr)
 	{
 		lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
-		p[0 * SDFR_BLOCK] = pr.dir.x; p[1 * SDFR_BLOCK] = pr.dir.y; p[2 * SDFR_BLOCK] = pr.dir.z;
-		p[3 * SDFR_BLOCK] = pr.right_ray.x; p[4 * SDFR_BLOCK] = pr.right_ray.y; p[5 * SDFR_BLOCK] = pr.right_ray.z;
-		p[6 * SDFR_BLOCK] = pr.bottom_ray.x; p[7 * SDFR_BLOCK] = pr.bottom_ray.y; p[8 * SDFR_BLOCK] = pr.bottom_ray.z;
+		p[0 * SDFR_BLOCK] = pr.right_ray.x; p[1 * SDFR_BLOCK] = pr.right_ray.y; p[2 * SDFR_BLOCK] = pr.right_ray.z;
+		p[3 * SDFR_BLOCK] = pr.bottom_ray.x; p[4 * SDFR_BLOCK] = pr.bottom_ray.y; p[5 * SDFR_BLOCK] = pr.bottom_ray.z;
 	}
 	__device__ __forceinline__ PixelRay pixel_ray_kept() const
 	{
 		const lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
 		PixelRay pr;
-		pr.dir = V3(p[0 * SDFR_BLOCK], p[1 * SDFR_BLOCK], p[2 * SDFR_BLOCK]);
-		pr.right_ray = V3(p[3 * SDFR_BLOCK], p[4 * SDFR_BLOCK], p[5 * SDFR_BLOCK]);
-		pr.bottom_ray = V3(p[6 * SDFR_BLOCK], p[7 * SDFR_BLOCK], p[8 * SDFR_BLOCK]);
+		pr.dir = V3s(0.f); // the primary direction is not needed after the prologue
+		pr.right_ray = V3(p[0 * SDFR_BLOCK], p[1 * SDFR_BLOCK], p[2 * SDFR_BLOCK]);
+		pr.bottom_ray = V3(p[3 * SDFR_BLOCK], p[4 * SDFR_BLOCK], p[5 * SDFR_BLOCK]);
 		return pr;
 	}
 };
