@@ -28,6 +28,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's cross-process buffer
+# sharing fails with hipIpcGetMemHandle (already exported by the image; kept for bare shells)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
