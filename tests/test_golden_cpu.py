@@ -130,3 +130,25 @@ def test_extension_lights_host_stages_match_oracle(oracle, scene):
     img, st = hostsim.render(scene, hostsim.frame_from_oracle(f))
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(st, rst)
+
+
+def _frames256():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames256.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("case", _frames256()["frames"], ids=lambda c: "%s-t%g%s" % (c["scene"], c["stime"], "-cfg1" if c["limits"] else ""))
+def test_oracle_reproduces_256x256_digests(oracle, case):
+    """256x256 start-up-camera frames of the configuration scenes, pinned by digest."""
+    import hashlib
+
+    f = oracle.default_frame(case["scene"], 256, 256, stime=case["stime"])
+    for k, v in case["limits"].items():
+        setattr(f, k, v)
+    img, st, tot = oracle.render(case["scene"], f, stats=True)
+    assert [int(x) for x in tot] == case["totals"]
+    assert hashlib.sha256(img.tobytes()).hexdigest() == case["rgba_sha256"]
+    assert hashlib.sha256(st.tobytes()).hexdigest() == case["stats_sha256"]

@@ -279,3 +279,34 @@ def test_variable_tables_of_all_scenes(oracle):
         want = [(row[0],) + tuple(float(np.float32(x)) for x in row[1:6]) for row in oracle.var_table(scene)]
         assert got == want, scene
     r.close()
+
+
+def _frames256():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames256.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("case", _frames256()["frames"], ids=lambda c: "%s-t%g%s" % (c["scene"], c["stime"], "-cfg1" if c["limits"] else ""))
+def test_kernels_reproduce_256x256_digests(renderer, case):
+    """The committed 256x256 digests (tools/make_golden256.py), no oracle involved: start-up camera
+    of the reference, both schedules."""
+    import hashlib
+
+    import sdf_playground_amd as sp
+
+    renderer.initShader(case["scene"])
+    renderer.setParameters(case["stime"])
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0)
+    renderer.setLimits(**case["limits"])
+    cam = sp.Camera()          # Application.cpp:214-224
+    cam.SetAspect(1.0)
+    for schedule in (sp.SCHEDULE_PIXEL, sp.SCHEDULE_WAVEFRONT):
+        renderer.setSchedule(schedule)
+        img, st = renderer.render(cam, 256, 256, pixel_stats=True)
+        assert hashlib.sha256(img.tobytes()).hexdigest() == case["rgba_sha256"], (case["scene"], schedule)
+        assert hashlib.sha256(st.tobytes()).hexdigest() == case["stats_sha256"]
+        s = renderer.getStats()
+        assert [s.pixels, s.rays, s.march_evals, s.hits] == case["totals"]
