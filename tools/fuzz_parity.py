@@ -1,0 +1,90 @@
+"""Randomised parity hunt (GPU box): random cameras, times, variable values and limits for every
+built-in scene, HIP kernels against the CPU oracle, bit for bit (pixels and per-pixel counters).
+The fixed-camera tests cannot find a culling bound or a fast-math domain that only fails from
+some other viewpoint; this can.  Prints every mismatch; exit status 1 if there was one.
+
+    python tools/fuzz_parity.py --cases 40 --seed 1"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import sdf_playground_amd as sp
+from oracle import pyoracle as po
+
+
+def run(cases, seed, size, scenes=None, verbose=False):
+    rng = np.random.default_rng(seed)
+    W, H = size
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    asp = np.float32(W) / np.float32(H)
+    r = sp.SDFRenderer(0)
+    bad = []
+    n = 0
+    for scene in (scenes or sp.scene_names()):
+        r.initShader(scene)
+        table = po.var_table(scene)
+        for c in range(cases):
+            # camera: somewhere in a box around the origin, looking roughly at the scene's middle
+            eye = (float(rng.uniform(-9, 9)), float(rng.uniform(0.2, 8)), float(rng.uniform(-9, 9)))
+            tgt = (float(rng.uniform(-2, 2)), float(rng.uniform(0, 3)), float(rng.uniform(-2, 2)))
+            if c % 5 == 4:  # sometimes from far away / from below the canopy / grazing the floor
+                eye = (float(rng.uniform(-40, 40)), float(rng.choice([0.05, 0.5, 25.0])), float(rng.uniform(-40, 40)))
+            stime = float(np.float32(rng.uniform(0, 30)))
+            basis = po.camera_lookat(eye, tgt, fovy, asp)
+            f = po.default_frame(scene, W, H, basis=basis, stime=stime)
+            limits = dict(iter_count=int(rng.choice([100, 100, 256, 37])), max_cost_default=int(rng.choice([7, 7, 9, 4])),
+                          ray_count=int(rng.choice([8, 8, 3])), bounce_count=int(rng.choice([16, 16, 5])),
+                          light_count=8, range=100.0, extension_lights=int(rng.choice([0, 0, 0, 7])))
+            for k, v in limits.items():
+                setattr(f, k, v)
+            r.setLimits(**limits)
+            r.setParameters(stime)
+            cam = sp.Camera()
+            cam.SetEye(eye)
+            cam.SetLookat(tgt)
+            cam.SetFOVY(float(fovy))
+            cam.SetAspect(float(asp))
+            r.resetVariables()
+            values = {}
+            for name, mn, mx, start, _st, _v, slot in table:
+                if slot >= 0 and rng.random() < 0.7:
+                    v = float(np.float32(rng.uniform(mn, mx)))
+                    values[name] = v
+                    f.scene_var[slot] = v
+                    r.setValue(name, v)
+            schedule = int(rng.integers(0, 2))
+            r.setSchedule(schedule)
+            img, st = r.render(cam, W, H, pixel_stats=True)
+            ref, rst, _ = po.render(scene, f, stats=True)
+            n += 1
+            same = np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(st, rst)
+            if not same:
+                # NaN payloads may differ in sign/payload bits: compare values with NaN == NaN as well
+                same = np.array_equal(img, ref, equal_nan=True) and np.array_equal(st, rst)
+            if not same:
+                diff = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+                bad.append((scene, c, eye, tgt, stime, limits, values, schedule, diff))
+                print("MISMATCH", bad[-1], flush=True)
+            elif verbose:
+                print("ok", scene, c, flush=True)
+        print("%-20s %d cases done, %d mismatches so far" % (scene, cases, len(bad)), flush=True)
+    r.close()
+    return n, bad
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--size", default="64x48")
+    ap.add_argument("--scenes", default="")
+    a = ap.parse_args()
+    w, h = (int(x) for x in a.size.split("x"))
+    n, bad = run(a.cases, a.seed, (w, h), [s for s in a.scenes.split(",") if s] or None)
+    print("%d cases, %d mismatches" % (n, len(bad)))
+    sys.exit(1 if bad else 0)
