@@ -102,7 +102,7 @@ static int ensure_workspace(sdfr_renderer *r, size_t pixels)
 	SDFR_HIP(hipMalloc((void **)&w.list_a, sizeof(uint32_t) * pixels));
 	SDFR_HIP(hipMalloc((void **)&w.list_b, sizeof(uint32_t) * pixels));
 	SDFR_HIP(hipMalloc((void **)&w.counters, sizeof(uint32_t) * 64));
-	SDFR_HIP(hipMalloc((void **)&w.partials, sizeof(RenderTotals) * (pixels / 256 + 1)));
+	SDFR_HIP(hipMalloc((void **)&w.partials, sizeof(RenderTotals) * (pixels / 64 + 1)));
 	w.pstat = nullptr;
 	r->ws = w;
 	return SDFR_OK;

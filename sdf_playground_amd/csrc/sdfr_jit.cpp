@@ -126,7 +126,8 @@ bool jit_compile_code(const std::string &arch_name, const std::string &name, con
 	// same code generation rules as the ahead-of-time build (buildlib.py): only explicit fma() fuses
 	const std::string arch = "--offload-arch=" + arch_name;
 	const std::string inc = "-I" + header_dir();
-	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", inc.c_str()};
+	const std::string block = "-DSDFR_PIXEL_BLOCK=" + std::to_string(pixel_block_threads()); // must match the launch
+	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", inc.c_str(), block.c_str()};
 	rc = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
 	size_t log_bytes = 0;
 	rtc.log_size(prog, &log_bytes);
@@ -193,14 +194,15 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 {
 	uint32_t n_work = launch_work_items(U.width, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
-	const uint32_t blocks = (n_work + 255u) / 256u;
+	const uint32_t bt = (uint32_t)pixel_block_threads();
+	const uint32_t blocks = (n_work + bt - 1u) / bt;
 	FrameU frame = U;
 	RowMap rows = rm;
 	float *queue = ws.ray_queue;
 	size_t cap = ws.capacity;
 	RenderTotals *partials = ws.partials;
 	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &queue, &cap};
-	const hipError_t e = hipModuleLaunchKernel(frame_needs_debug(U) ? js.pixel_debug : js.pixel, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+	const hipError_t e = hipModuleLaunchKernel(frame_needs_debug(U) ? js.pixel_debug : js.pixel, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
 	return launch_reduce_totals(partials, blocks, totals, stream);
 }

@@ -41,6 +41,7 @@ hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatc
 
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream);
 
+int pixel_block_threads(); // block size of the pixel kernels (partials are sized by it)
 int device_cu_count(int device);
 // work items (padded to whole tiles) of a launch: lists and per-pixel state are sized by this
 uint32_t launch_work_items(int width, const RowMap &rm);

@@ -432,6 +432,8 @@ hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatc
 // =================================================================================================
 // launchers
 // =================================================================================================
+int pixel_block_threads() { return SDFR_PIXEL_BLOCK; }
+
 int device_cu_count(int device)
 {
 	hipDeviceProp_t prop;
@@ -445,8 +447,8 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 {
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
-	const uint32_t blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, ws.ray_queue,
+	const uint32_t blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, ws.ray_queue,
 		ws.capacity);
 	return launch_reduce_totals(ws.partials, blocks, totals, stream);
 }

@@ -11,6 +11,13 @@
 namespace sdfr {
 
 #define SDFR_BLOCK 256
+// Threads per block of the pixel kernels.  One wave per block: nothing in the kernel needs a
+// larger group, and a block holds its registers and LDS until its LAST wave ends, which with
+// step counts this uneven leaves slots idle (measured at 4K, 256 -> 64 threads: labyrinth -1.5 %,
+// fractal and lense -4 %, the larger fold of the per-block counters included).
+#ifndef SDFR_PIXEL_BLOCK
+#define SDFR_PIXEL_BLOCK 64
+#endif
 #define SDFR_INVALID_PIXEL 0xffffffffu
 // Launch attributes of every pixel kernel.  The register allocator is held to 7 waves per SIMD
 // (<= 72 VGPRs; left alone it takes ~100-160 and fits 3-4): the VALU of gfx950 issues one
@@ -24,7 +31,7 @@ namespace sdfr {
 #ifndef SDFR_PIXEL_WAVES_PER_EU
 #define SDFR_PIXEL_WAVES_PER_EU 7
 #endif
-#define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
+#define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_PIXEL_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
 
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
@@ -165,25 +172,25 @@ typedef __attribute__((address_space(3))) float lds_float;
 struct LdsCachedRayStore
 {
 	GlobalRayStore &backing;
-	lds_float *lds; // this thread's column of the block's [17][SDFR_BLOCK] array
+	lds_float *lds; // this thread's column of the block's [17][SDFR_PIXEL_BLOCK] array
 	int cached_slot;
 	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column) : backing(b), lds((lds_float *)column), cached_slot(-1) {}
 	__device__ __forceinline__ void write_rec(const RayRec &r)
 	{
-		lds[0 * SDFR_BLOCK] = r.pos.x; lds[1 * SDFR_BLOCK] = r.pos.y; lds[2 * SDFR_BLOCK] = r.pos.z;
-		lds[3 * SDFR_BLOCK] = r.dir.x; lds[4 * SDFR_BLOCK] = r.dir.y; lds[5 * SDFR_BLOCK] = r.dir.z;
-		lds[6 * SDFR_BLOCK] = r.contrib.x; lds[7 * SDFR_BLOCK] = r.contrib.y; lds[8 * SDFR_BLOCK] = r.contrib.z;
-		lds[9 * SDFR_BLOCK] = r.shadow_range;
-		lds[10 * SDFR_BLOCK] = __uint_as_float(r.bits);
+		lds[0 * SDFR_PIXEL_BLOCK] = r.pos.x; lds[1 * SDFR_PIXEL_BLOCK] = r.pos.y; lds[2 * SDFR_PIXEL_BLOCK] = r.pos.z;
+		lds[3 * SDFR_PIXEL_BLOCK] = r.dir.x; lds[4 * SDFR_PIXEL_BLOCK] = r.dir.y; lds[5 * SDFR_PIXEL_BLOCK] = r.dir.z;
+		lds[6 * SDFR_PIXEL_BLOCK] = r.contrib.x; lds[7 * SDFR_PIXEL_BLOCK] = r.contrib.y; lds[8 * SDFR_PIXEL_BLOCK] = r.contrib.z;
+		lds[9 * SDFR_PIXEL_BLOCK] = r.shadow_range;
+		lds[10 * SDFR_PIXEL_BLOCK] = __uint_as_float(r.bits);
 	}
 	__device__ __forceinline__ RayRec read_rec() const
 	{
 		RayRec r;
-		r.pos = V3(lds[0 * SDFR_BLOCK], lds[1 * SDFR_BLOCK], lds[2 * SDFR_BLOCK]);
-		r.dir = V3(lds[3 * SDFR_BLOCK], lds[4 * SDFR_BLOCK], lds[5 * SDFR_BLOCK]);
-		r.contrib = V3(lds[6 * SDFR_BLOCK], lds[7 * SDFR_BLOCK], lds[8 * SDFR_BLOCK]);
-		r.shadow_range = lds[9 * SDFR_BLOCK];
-		r.bits = __float_as_uint(lds[10 * SDFR_BLOCK]);
+		r.pos = V3(lds[0 * SDFR_PIXEL_BLOCK], lds[1 * SDFR_PIXEL_BLOCK], lds[2 * SDFR_PIXEL_BLOCK]);
+		r.dir = V3(lds[3 * SDFR_PIXEL_BLOCK], lds[4 * SDFR_PIXEL_BLOCK], lds[5 * SDFR_PIXEL_BLOCK]);
+		r.contrib = V3(lds[6 * SDFR_PIXEL_BLOCK], lds[7 * SDFR_PIXEL_BLOCK], lds[8 * SDFR_PIXEL_BLOCK]);
+		r.shadow_range = lds[9 * SDFR_PIXEL_BLOCK];
+		r.bits = __float_as_uint(lds[10 * SDFR_PIXEL_BLOCK]);
 		return r;
 	}
 	__device__ __forceinline__ void put(int i, const RayRec &r)
@@ -203,17 +210,17 @@ struct LdsCachedRayStore
 	}
 	__device__ __forceinline__ void keep_pixel_ray(const PixelRay &pr)
 	{
-		lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
-		p[0 * SDFR_BLOCK] = pr.right_ray.x; p[1 * SDFR_BLOCK] = pr.right_ray.y; p[2 * SDFR_BLOCK] = pr.right_ray.z;
-		p[3 * SDFR_BLOCK] = pr.bottom_ray.x; p[4 * SDFR_BLOCK] = pr.bottom_ray.y; p[5 * SDFR_BLOCK] = pr.bottom_ray.z;
+		lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_PIXEL_BLOCK;
+		p[0 * SDFR_PIXEL_BLOCK] = pr.right_ray.x; p[1 * SDFR_PIXEL_BLOCK] = pr.right_ray.y; p[2 * SDFR_PIXEL_BLOCK] = pr.right_ray.z;
+		p[3 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.x; p[4 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.y; p[5 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.z;
 	}
 	__device__ __forceinline__ PixelRay pixel_ray_kept() const
 	{
-		const lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_BLOCK;
+		const lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_PIXEL_BLOCK;
 		PixelRay pr;
 		pr.dir = V3s(0.f); // the primary direction is not needed after the prologue
-		pr.right_ray = V3(p[0 * SDFR_BLOCK], p[1 * SDFR_BLOCK], p[2 * SDFR_BLOCK]);
-		pr.bottom_ray = V3(p[3 * SDFR_BLOCK], p[4 * SDFR_BLOCK], p[5 * SDFR_BLOCK]);
+		pr.right_ray = V3(p[0 * SDFR_PIXEL_BLOCK], p[1 * SDFR_PIXEL_BLOCK], p[2 * SDFR_PIXEL_BLOCK]);
+		pr.bottom_ray = V3(p[3 * SDFR_PIXEL_BLOCK], p[4 * SDFR_PIXEL_BLOCK], p[5 * SDFR_PIXEL_BLOCK]);
 		return pr;
 	}
 };
@@ -224,8 +231,8 @@ template <class Scene, bool DBG>
 __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *partials, float *ray_queue, size_t cap)
 {
-	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_BLOCK];
-	const uint32_t w = blockIdx.x * SDFR_BLOCK + threadIdx.x;
+	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
+	const uint32_t w = blockIdx.x * SDFR_PIXEL_BLOCK + threadIdx.x;
 	PixelCounters c = {};
 	uint32_t npix = 0;
 	PixelCoord pc;
