@@ -90,11 +90,11 @@ std::string jit_translation_unit(const std::string &scene_source, const std::vec
 	tu += "\n#line 1 \"sdfr_jit_kernels\"\n";
 	tu += "extern \"C\" __global__ void sdfr_jit_prepare(FrameU *U) { if (blockIdx.x == 0 && threadIdx.x == 0) Scene::prepare(*U); }\n";
 	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, float *ray_queue, size_t cap)\n"
-		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, ray_queue, cap); }\n";
+		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)\n"
+		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap); }\n";
 	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, float *ray_queue, size_t cap)\n"
-		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, ray_queue, cap); }\n";
+		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)\n"
+		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap); }\n";
 	tu += "} // namespace sdfr\n";
 	return tu;
 }
@@ -201,7 +201,7 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	float *queue = ws.ray_queue;
 	size_t cap = ws.capacity;
 	RenderTotals *partials = ws.partials;
-	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &queue, &cap};
+	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap};
 	const hipError_t e = hipModuleLaunchKernel(frame_needs_debug(U) ? js.pixel_debug : js.pixel, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
 	return launch_reduce_totals(partials, blocks, totals, stream);

@@ -49,16 +49,16 @@ static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_wo
 // =================================================================================================
 template <class Scene, bool DBG>
 __global__ SDFR_PIXEL_KERNEL_ATTRS void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, float *ray_queue, size_t cap)
+	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)
 {
-	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, ray_queue, cap);
+	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap);
 }
 
-// folds the per-block partial sums of a pixel-schedule launch into the render totals (overwrites
-// them: no memset needed).  One block; every thread keeps 8 independent 32-byte loads in flight,
-// so the ~1 MB of partials of a 4K frame takes a few microseconds instead of a chain of
-// dependent round trips.
-#define SDFR_REDUCE_THREADS 1024
+// Folds the per-block partial sums of a pixel-schedule launch (one 32-byte record per wave: 4 MB
+// at 4K) into the render totals, which the pixel kernel has cleared: a few blocks, each keeping
+// several independent loads in flight per thread, then ONE set of four atomics per block.
+#define SDFR_REDUCE_THREADS 256
+#define SDFR_REDUCE_BLOCKS 64
 __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals)
 {
 	__shared__ unsigned long long acc[4];
@@ -66,17 +66,18 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 	__syncthreads();
 	unsigned long long s[4] = {0ull, 0ull, 0ull, 0ull};
 	const ulonglong4 *src = reinterpret_cast<const ulonglong4 *>(partials);
-	for (uint32_t base = threadIdx.x; base < n; base += SDFR_REDUCE_THREADS * 8)
+	const uint32_t stride = gridDim.x * SDFR_REDUCE_THREADS;
+	for (uint32_t base = blockIdx.x * SDFR_REDUCE_THREADS + threadIdx.x; base < n; base += stride * 4)
 	{
-		ulonglong4 v[8];
+		ulonglong4 v[4];
 #pragma unroll
-		for (int k = 0; k < 8; ++k)
+		for (int k = 0; k < 4; ++k)
 		{
-			const uint32_t i = base + (uint32_t)k * SDFR_REDUCE_THREADS;
+			const uint32_t i = base + (uint32_t)k * stride;
 			v[k] = i < n ? src[i] : make_ulonglong4(0ull, 0ull, 0ull, 0ull);
 		}
 #pragma unroll
-		for (int k = 0; k < 8; ++k)
+		for (int k = 0; k < 4; ++k)
 		{
 			s[0] += v[k].x;
 			s[1] += v[k].y;
@@ -89,11 +90,14 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 	if ((threadIdx.x & 63) == 0)
 		for (int k = 0; k < 4; ++k) atomicAdd(&acc[k], s[k]);
 	__syncthreads();
-	if (threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = acc[threadIdx.x];
+	if (threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(totals) + threadIdx.x, acc[threadIdx.x]);
 }
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_reduce_totals, dim3(1), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals);
+	uint32_t blocks = (n_blocks + SDFR_REDUCE_THREADS * 4 - 1) / (SDFR_REDUCE_THREADS * 4);
+	if (blocks > SDFR_REDUCE_BLOCKS) blocks = SDFR_REDUCE_BLOCKS;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals);
 	return hipGetLastError();
 }
 
@@ -448,8 +452,8 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
 	const uint32_t blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, ws.ray_queue,
-		ws.capacity);
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, totals,
+		ws.ray_queue, ws.capacity);
 	return launch_reduce_totals(ws.partials, blocks, totals, stream);
 }
 

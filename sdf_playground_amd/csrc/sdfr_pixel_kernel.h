@@ -229,8 +229,10 @@ struct LdsCachedRayStore
 // sdfr_kernels.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
 template <class Scene, bool DBG>
 __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, float *ray_queue, size_t cap)
+	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)
 {
+	// the fold kernel that follows adds into the totals: clear them here (kernel boundary = ordering)
+	if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = 0ull;
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
 	const uint32_t w = blockIdx.x * SDFR_PIXEL_BLOCK + threadIdx.x;
 	PixelCounters c = {};
