@@ -81,15 +81,40 @@ def load_census():
         return None
 
 
-def cpu_baseline(max_seconds=15.0):
+def host_cores():
+    """CPUs this process may really use: the scheduler affinity and the cgroup CPU quota both
+    cap it (a GPU box reports every core of the host but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max":
+                n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, int(math.ceil(q / per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(max_seconds=20.0):
     """The CPU oracle (a port: the reference HLSL cannot run here) timed on the host cores on a
-    bounded sample of the same workload: sweep frames 0..7 (fewer on slow hosts: it stops after
-    max_seconds), every 2nd pixel in x and y."""
+    bounded sample of the same workload: the 16 sweep frames (fewer on slow hosts: it stops after
+    max_seconds), every 2nd pixel in x and y; threads = the CPUs the cgroup really grants."""
     from oracle import pyoracle as po
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     step = 2
-    frames = 8
+    frames = SWEEP
     rays = 0
     pixels = 0
     t_total = 0.0
