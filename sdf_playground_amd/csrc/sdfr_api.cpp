@@ -43,6 +43,7 @@ struct sdfr_renderer
 
 	RenderTotals *d_totals = nullptr;
 	WavefrontWorkspace ws = {};
+	size_t wavefront_capacity = 0; // pixels the wavefront-only part of `ws` is allocated for
 	void *d_stage = nullptr; // staging image for host-destination renders
 	size_t stage_bytes = 0;
 	uint32_t *d_pstat = nullptr;
@@ -85,26 +86,46 @@ static void free_workspace(sdfr_renderer *r)
 	(void)hipFree(w.counters);
 	(void)hipFree(w.partials);
 	w = WavefrontWorkspace{};
+	r->wavefront_capacity = 0;
 }
 
-static int ensure_workspace(sdfr_renderer *r, size_t pixels)
+// Per-pixel scratch sized for `pixels` work items.  Both schedules use the pending-ray queue and
+// the counter partials; the per-round state of the wavefront schedule (another 116 B per pixel)
+// is allocated only once that schedule is used.  On failure everything is released (hipFree
+// waits for the device, so buffers of frames still in flight are safe to drop).
+static int ensure_workspace(sdfr_renderer *r, size_t pixels, bool wavefront)
 {
-	if (r->ws.capacity >= pixels) return SDFR_OK;
-	free_workspace(r);
-	WavefrontWorkspace w = {};
-	w.capacity = pixels;
-	SDFR_HIP(hipMalloc((void **)&w.ray_cur, sizeof(float) * 11 * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.ray_queue, sizeof(float) * 11 * SDFR_MAX_RAYS * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.qdepth_lo, sizeof(uint32_t) * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.qdepth_hi, sizeof(uint32_t) * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.result, sizeof(float) * 8 * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.accum, sizeof(float) * 4 * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.list_a, sizeof(uint32_t) * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.list_b, sizeof(uint32_t) * pixels));
-	SDFR_HIP(hipMalloc((void **)&w.counters, sizeof(uint32_t) * 64));
-	SDFR_HIP(hipMalloc((void **)&w.partials, sizeof(RenderTotals) * (pixels / 64 + 1)));
-	w.pstat = nullptr;
-	r->ws = w;
+	WavefrontWorkspace &w = r->ws;
+	if (w.capacity < pixels || (wavefront && r->wavefront_capacity < pixels))
+	{
+		if (w.capacity < pixels) free_workspace(r);
+		const size_t n = w.capacity < pixels ? pixels : w.capacity;
+		hipError_t e = hipSuccess;
+		auto alloc = [&](void **p, size_t bytes) {
+			if (e == hipSuccess && *p == nullptr) e = hipMalloc(p, bytes);
+		};
+		alloc((void **)&w.ray_queue, sizeof(float) * 11 * SDFR_MAX_RAYS * n);
+		alloc((void **)&w.partials, sizeof(RenderTotals) * (n / 64 + 1));
+		if (wavefront)
+		{
+			alloc((void **)&w.ray_cur, sizeof(float) * 11 * n);
+			alloc((void **)&w.qdepth_lo, sizeof(uint32_t) * n);
+			alloc((void **)&w.qdepth_hi, sizeof(uint32_t) * n);
+			alloc((void **)&w.result, sizeof(float) * 8 * n);
+			alloc((void **)&w.accum, sizeof(float) * 4 * n);
+			alloc((void **)&w.list_a, sizeof(uint32_t) * n);
+			alloc((void **)&w.list_b, sizeof(uint32_t) * n);
+			alloc((void **)&w.counters, sizeof(uint32_t) * 64);
+		}
+		if (e != hipSuccess)
+		{
+			free_workspace(r);
+			return hip_fail(r, e, "workspace allocation");
+		}
+		w.capacity = n;
+		if (wavefront) r->wavefront_capacity = n;
+		w.pstat = nullptr;
+	}
 	return SDFR_OK;
 }
 
@@ -514,7 +535,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;
-	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm));
+	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm), !pixel_schedule);
 	if (rc != SDFR_OK) return rc;
 	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->scene == SDFR_SCENE_COUNT) // scenes compiled at run time exist for the PIXEL schedule only
