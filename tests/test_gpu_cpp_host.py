@@ -34,3 +34,28 @@ def test_cpp_host_mirror_reproduces_golden(tmp_path):
         assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32)), scene
         if scene == "lense":
             assert "mixing=0.5" in r.stdout and "zpos=12.5" in r.stdout
+
+
+def test_cpp_host_compiles_a_scene_file_at_run_time(tmp_path):
+    """sdfr::SDFRenderer::initShaderSource from a plain g++ program: the text of the built-in
+    fast_sphere scene, written to a file, must reproduce that scene's golden fixture."""
+    import sdf_playground_amd as sp
+    from jit_util import aot_scene_source
+
+    exe = str(tmp_path / "host_reload")
+    libdir = os.path.dirname(sp.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_reload.cpp"),
+                    "-L" + libdir, "-lsdfr", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    src = str(tmp_path / "fast_sphere.scene.h")
+    with open(src, "w") as fh:
+        fh.write(aot_scene_source("SceneFastSphere"))
+    path = [p for p in gu.golden_files() if gu.scene_of(p) == "fast_sphere"][0]
+    g = np.load(path)
+    assert not bool(g["target_is_direction"])
+    out = str(tmp_path / "img.raw")
+    args = [exe, src, repr(float(g["stime"])), str(int(g["width"])), out] + [repr(float(x)) for x in g["eye"]] + [repr(float(x)) for x in g["target"]]
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    img = np.fromfile(out, np.float32).reshape(g["rgba"].shape)
+    assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32))
