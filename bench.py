@@ -194,9 +194,10 @@ def main():
         rr[1].setLimits(iter_count=ITER_COUNT)
         rr[1].setSchedule(schedule)
         rr[1].setStream(rs[1].cuda_stream)
-        n_local = sp.strip_buffer_pixels(W, H, world)
-        local = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-        gathered_flat = [torch.empty((world, n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else None
+        # strips travel in the packed lossless format: 13 bytes per pixel instead of 16 (alpha is a flag)
+        n_bytes = sp.strip_buffer_bytes(W, H, world, sp.STRIP_RGB32F_A8)
+        local = [torch.empty((n_bytes,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gathered_flat = [torch.empty((world, n_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
         gather_lists = [list(g.unbind(0)) for g in gathered_flat] if rank == 0 else None
         works = [None, None]
         side = torch.cuda.Stream()
@@ -226,12 +227,12 @@ def main():
                 works[b].wait()                    # this frame's stream: local[b] is free once gather s-2 is done
             if rank == 0 and asm_used[b]:
                 rs[b].wait_event(asm_done[b])      # gathered_flat[b] is free once assembly s-2 is done
-            h.renderStrips(W, H, rank, world, local[b])
+            h.renderStrips(W, H, rank, world, local[b], fmt=sp.STRIP_RGB32F_A8)
             if rank == 0:
                 works[b] = dist.gather(local[b], gather_list=gather_lists[b], dst=0, async_op=True)
                 with torch.cuda.stream(side):
                     works[b].wait()
-                    r_asm.assembleStrips(W, H, world, gathered_flat[b], image)
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], image, fmt=sp.STRIP_RGB32F_A8)
                     asm_done[b].record(side)
                     asm_used[b] = True
             else:

@@ -124,7 +124,12 @@ int sdfr_set_profiling(sdfr_renderer *r, int enabled);
 typedef enum sdfr_format
 {
 	SDFR_RGBA32F = 0, /* what the shader computes */
-	SDFR_RGBA16F = 1  /* what the reference's render target stores */
+	SDFR_RGBA16F = 1, /* what the reference's render target stores */
+	/* strips only (sdfr_render_strips / sdfr_assemble_strips): the RGBA32F frame in 13 bytes per pixel,
+	 * lossless -- rgb as three floats, then one byte per pixel for alpha, which is the tone-map flag
+	 * (pshader_sdf.hlsl:357-359, 0 or 1).  19 % fewer bytes through the inter-GPU gather; assembles
+	 * into an RGBA32F image. */
+	SDFR_STRIP_RGB32F_A8 = 2
 } sdfr_format;
 
 /* Render a width x height frame into `out` (device pointer if out_on_host == 0, else host).
@@ -139,6 +144,7 @@ int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, 
  * reference is single-GPU; this is the sharding of SURVEY.md 8(e). */
 #define SDFR_STRIP_ROWS 8
 int64_t sdfr_strip_buffer_pixels(int width, int height, int world);
+int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format); /* bytes of one rank's compact buffer */
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format);
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format);
 

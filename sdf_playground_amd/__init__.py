@@ -27,6 +27,7 @@ SCHEDULE_WAVEFRONT = 0
 SCHEDULE_PIXEL = 1
 RGBA32F = 0
 RGBA16F = 1
+STRIP_RGB32F_A8 = 2  # strips only: rgb float triples + one flag byte per pixel (lossless, 13 B/pixel)
 STRIP_ROWS = 8
 
 _STATUS = {
@@ -69,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
 ]
 
 _lib = None
@@ -127,6 +128,8 @@ def load_library():
     L.sdfr_set_profiling.argtypes = [vp, ci]
     L.sdfr_strip_buffer_pixels.argtypes = [ci, ci, ci]
     L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
+    L.sdfr_strip_buffer_bytes.argtypes = [ci, ci, ci, ci]
+    L.sdfr_strip_buffer_bytes.restype = ctypes.c_int64
     L.sdfr_render.argtypes = [vp, ci, ci, vp, ci, ci, vp]
     L.sdfr_render_strips.argtypes = [vp, ci, ci, ci, ci, vp, ci]
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
@@ -156,6 +159,11 @@ def check_scene_source(source, arch="gfx950"):
 
 def strip_buffer_pixels(width, height, world):
     return int(load_library().sdfr_strip_buffer_pixels(width, height, world))
+
+
+def strip_buffer_bytes(width, height, world, fmt):
+    """Bytes of one rank's compact strip buffer in format `fmt` (RGBA32F, RGBA16F or STRIP_RGB32F_A8)."""
+    return int(load_library().sdfr_strip_buffer_bytes(width, height, world, fmt))
 
 
 def _f3(v):
@@ -366,7 +374,7 @@ class SDFRenderer:
 
     def renderStrips(self, width, height, rank, world, out, fmt=RGBA32F):
         """Multi-GPU: render this rank's 8-row strips into the compact device tensor `out`."""
-        assert out.is_cuda and out.is_contiguous() and out.numel() == strip_buffer_pixels(width, height, world) * 4
+        assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() == strip_buffer_bytes(width, height, world, fmt)
         self._check(self._L.sdfr_render_strips(self._h, width, height, rank, world, ctypes.c_void_p(out.data_ptr()), fmt))
         return out
 

@@ -72,6 +72,14 @@ static int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
 #define SDFR_HIP(call) \
 	do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(r, e_, #call); } while (0)
 
+// bytes of a compact image of `pixels` pixels (per rank, for the packed format padded to 4)
+static size_t image_bytes(size_t pixels, int format)
+{
+	if (format == SDFR_RGBA32F) return pixels * 16;
+	if (format == SDFR_RGBA16F) return pixels * 8;
+	return (pixels * 13 + 3) & ~(size_t)3;
+}
+
 static void free_workspace(sdfr_renderer *r)
 {
 	WavefrontWorkspace &w = r->ws;
@@ -450,6 +458,13 @@ int sdfr_set_schedule(sdfr_renderer *r, int schedule)
 	return SDFR_OK;
 }
 
+int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format)
+{
+	const int64_t n = sdfr_strip_buffer_pixels(width, height, world);
+	if (n < 0 || (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8)) return -1;
+	return (int64_t)image_bytes((size_t)n, format);
+}
+
 int64_t sdfr_strip_buffer_pixels(int width, int height, int world)
 {
 	if (width < 1 || height < 1 || world < 1) return 0;
@@ -483,10 +498,12 @@ static int latch_frame(sdfr_renderer *r, int width, int height)
 	return SDFR_OK;
 }
 
-static int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats)
+static int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
+	bool strips)
 {
 	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && !(strips && format == SDFR_STRIP_RGB32F_A8))
+		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	if (world < 1 || rank < 0 || rank >= world) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad rank/world");
 	SDFR_HIP(hipSetDevice(r->device));
 	const auto t_setup = std::chrono::steady_clock::now();
@@ -499,21 +516,21 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	rm.world = world;
 	rm.tile_w_log2 = r->tile_w_log2;
 	rm.local_rows = (int)(sdfr_strip_buffer_pixels(width, height, world) / width);
-	if (world == 1) rm.local_rows = height;
+	if (world == 1 && !strips) rm.local_rows = height; // a strip buffer keeps whole strips (rows past the frame stay zero)
 	const size_t local_pixels = (size_t)rm.local_rows * width;
-	const size_t bpp = format == SDFR_RGBA32F ? 16 : 8;
+	const size_t out_bytes = image_bytes(local_pixels, format);
 
 	void *d_out = out;
 	uint32_t *d_pstat = pixel_stats;
 	if (out_on_host)
 	{
-		if (r->stage_bytes < local_pixels * bpp)
+		if (r->stage_bytes < out_bytes)
 		{
 			(void)hipFree(r->d_stage);
 			r->d_stage = nullptr;
 			r->stage_bytes = 0;
-			SDFR_HIP(hipMalloc(&r->d_stage, local_pixels * bpp));
-			r->stage_bytes = local_pixels * bpp;
+			SDFR_HIP(hipMalloc(&r->d_stage, out_bytes));
+			r->stage_bytes = out_bytes;
 		}
 		d_out = r->d_stage;
 		if (pixel_stats)
@@ -530,7 +547,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 		}
 	}
 	if (world > 1) // strips past the end of the frame are never written: define them
-		SDFR_HIP(hipMemsetAsync(d_out, 0, local_pixels * bpp, r->stream));
+		SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
 
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
@@ -561,7 +578,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 
 	if (out_on_host)
 	{
-		SDFR_HIP(hipMemcpyAsync(out, d_out, local_pixels * bpp, hipMemcpyDeviceToHost, r->stream));
+		SDFR_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, r->stream));
 		if (pixel_stats) SDFR_HIP(hipMemcpyAsync(pixel_stats, d_pstat, local_pixels * 12, hipMemcpyDeviceToHost, r->stream));
 		SDFR_HIP(hipStreamSynchronize(r->stream));
 	}
@@ -570,18 +587,18 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 
 int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
 {
-	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats);
+	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, false);
 }
 
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format)
 {
-	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr);
+	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr, true);
 }
 
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format)
 {
 	if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
-	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	SDFR_HIP(hipSetDevice(r->device));
 	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->stream);
 	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");

@@ -105,6 +105,6 @@ struct RowMap
 	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
 };
 
-enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1 };
+enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1, FORMAT_STRIP_RGB32F_A8 = 2 };
 
 } // namespace sdfr

@@ -64,11 +64,22 @@ __device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, 
 	px = (int)(pid - lrow * (uint32_t)U.width);
 	py = (int)(((lrow >> 3) * (uint32_t)rm.world + (uint32_t)rm.rank) * 8u + (lrow & 7u));
 }
-__device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid, vec4 c)
+// n_pixels = pixels of this launch's (compact) image: the packed strip format keeps its flag
+// bytes behind the n_pixels rgb triples
+__device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid, vec4 c, uint32_t n_pixels)
 {
 	if (format == FORMAT_RGBA32F)
 	{
 		reinterpret_cast<float4 *>(out)[pid] = make_float4(c.x, c.y, c.z, c.w);
+	}
+	else if (format == FORMAT_STRIP_RGB32F_A8)
+	{
+		// lossless 13 bytes per pixel for the inter-GPU gather: alpha is the hdr flag, 0 or 1
+		float *rgb = reinterpret_cast<float *>(out) + 3 * (size_t)pid;
+		rgb[0] = c.x;
+		rgb[1] = c.y;
+		rgb[2] = c.z;
+		reinterpret_cast<unsigned char *>(out)[12 * (size_t)n_pixels + pid] = c.w != 0.f ? 1 : 0;
 	}
 	else
 	{
@@ -243,7 +254,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		GlobalRayStore backing = {ray_queue, cap, pc.pid};
 		LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
 		vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, c, store);
-		store_pixel(out, format, pc.pid, v);
+		store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
 		if (pixel_stats)
 		{
 			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;

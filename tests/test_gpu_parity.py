@@ -218,6 +218,26 @@ def test_strip_sharding_matches_full_frame(renderer, oracle, world):
     assert torch.equal(out, full)
     # the host statement of the layout (used by the CPU multi-rank tests) agrees
     assert np.array_equal(sp.assemble_strips_host(w, h, world, gathered.cpu().numpy()), full.cpu().numpy())
+    # packed strips (13 bytes per pixel: rgb floats + the alpha flag as a byte) assemble to the same bits,
+    # for both schedules and also for the fp16 strips
+    nbytes = sp.strip_buffer_bytes(w, h, world, sp.STRIP_RGB32F_A8)
+    assert nbytes == (13 * n + 3) // 4 * 4 and sp.strip_buffer_bytes(w, h, world, sp.RGBA32F) == 16 * n
+    for schedule in (0, 1):
+        renderer.setSchedule(schedule)
+        packed = torch.full((world, nbytes), 0xAB, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            renderer.renderStrips(w, h, rank, world, packed[rank], fmt=sp.STRIP_RGB32F_A8)
+        out.zero_()
+        renderer.assembleStrips(w, h, world, packed, out, fmt=sp.STRIP_RGB32F_A8)
+        renderer.sync()
+        assert torch.equal(out.view(torch.int32), full.view(torch.int32)), schedule
+    half = torch.empty((world, n, 4), dtype=torch.float16, device="cuda")
+    for rank in range(world):
+        renderer.renderStrips(w, h, rank, world, half[rank], fmt=sp.RGBA16F)
+    out16 = torch.empty((h, w, 4), dtype=torch.float16, device="cuda")
+    renderer.assembleStrips(w, h, world, half, out16, fmt=sp.RGBA16F)
+    renderer.sync()
+    assert torch.equal(out16, full.to(torch.float16))
 
 
 def test_error_behaviour(oracle):
