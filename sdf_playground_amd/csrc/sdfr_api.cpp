@@ -546,8 +546,14 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 			d_pstat = r->d_pstat;
 		}
 	}
-	if (world > 1) // strips past the end of the frame are never written: define them
-		SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
+	if (strips)
+	{
+		// rows of the buffer past the end of the frame are never written: define them (only the ranks
+		// whose last strip is missing or cut short have any)
+		const int last_local_strip = rm.local_rows / SDFR_STRIP_ROWS - 1;
+		const long long last_row_end = ((long long)last_local_strip * world + rank) * SDFR_STRIP_ROWS + SDFR_STRIP_ROWS;
+		if (last_row_end > height) SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
+	}
 
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
