@@ -460,6 +460,26 @@ def assemble_strips_host(width, height, world, gathered):
     return img
 
 
+def pack_strip_host(compact_rgba):
+    """Host statement of SDFR_STRIP_RGB32F_A8: [n, 4] float32 (alpha 0 or 1) -> uint8 buffer of
+    (13 n + 3) // 4 * 4 bytes: n rgb float triples, then n flag bytes."""
+    c = np.ascontiguousarray(compact_rgba, np.float32).reshape(-1, 4)
+    n = c.shape[0]
+    out = np.zeros(((13 * n + 3) // 4 * 4,), np.uint8)
+    out[:12 * n] = np.ascontiguousarray(c[:, :3]).view(np.uint8).reshape(-1)
+    out[12 * n:13 * n] = (c[:, 3] != 0).astype(np.uint8)
+    return out
+
+
+def unpack_strip_host(packed, n):
+    """Inverse of pack_strip_host: -> [n, 4] float32."""
+    packed = np.asarray(packed, np.uint8)
+    c = np.zeros((n, 4), np.float32)
+    c[:, :3] = packed[:12 * n].view(np.float32).reshape(n, 3)
+    c[:, 3] = packed[12 * n:13 * n].astype(np.float32)
+    return c
+
+
 def strip_buffer_pixels_host(width, height, world):
     strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
     return ((strips + world - 1) // world) * STRIP_ROWS * width

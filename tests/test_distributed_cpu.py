@@ -43,11 +43,13 @@ def _worker(rank, world, port, out_path):
     for row in rows:
         strip = row // sp.STRIP_ROWS
         local[(strip // world) * sp.STRIP_ROWS + row % sp.STRIP_ROWS] = full[row]
-    t = torch.from_numpy(local.reshape(n, 4))
+    # strips travel packed (13 bytes per pixel, uint8 tensors) exactly as in bench.py
+    t = torch.from_numpy(sp.pack_strip_host(local.reshape(n, 4)))
     if rank == 0:
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.gather(t, gather_list=gathered, dst=0)
-        img = sp.assemble_strips_host(W, H, world, torch.stack(gathered).numpy())
+        unpacked = np.stack([sp.unpack_strip_host(g.numpy(), n) for g in gathered])
+        img = sp.assemble_strips_host(W, H, world, unpacked)
         np.save(out_path, img)
     else:
         dist.gather(t, dst=0)

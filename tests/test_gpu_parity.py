@@ -231,6 +231,9 @@ def test_strip_sharding_matches_full_frame(renderer, oracle, world):
         renderer.assembleStrips(w, h, world, packed, out, fmt=sp.STRIP_RGB32F_A8)
         renderer.sync()
         assert torch.equal(out.view(torch.int32), full.view(torch.int32)), schedule
+        # the host statement of the packed layout (CPU multi-rank test) agrees byte for byte
+        for rank in range(world):
+            assert np.array_equal(sp.pack_strip_host(gathered[rank].cpu().numpy()), packed[rank].cpu().numpy())
     half = torch.empty((world, n, 4), dtype=torch.float16, device="cuda")
     for rank in range(world):
         renderer.renderStrips(w, h, rank, world, half[rank], fmt=sp.RGBA16F)
