@@ -37,3 +37,18 @@ def test_scene_files_of_the_reference_declare_what_the_library_serves(oracle):
         assert sorted(table) == sorted(declared), stem
         for k, v in declared.items():
             assert tuple(np.float32(x) for x in v) == tuple(np.float32(x) for x in table[k]), (stem, k)
+
+
+def test_cli_checks_a_scene_source_without_a_gpu(tmp_path, capsys):
+    """--scene-source FILE --check compiles a run-time scene for gfx950 on a machine without a GPU."""
+    import os
+
+    from sdf_playground_amd import cli
+
+    good = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdf_playground_amd", "scenes", "pendulum.scene.h")
+    assert cli.main(["--scene-source", good, "--check"]) == 0
+    assert capsys.readouterr().out.strip() == "ok"
+    bad = tmp_path / "bad.scene.h"
+    bad.write_text(open(good).read().replace("ground_setup(dir)", "ground_setup(dirr)"))
+    assert cli.main(["--scene-source", str(bad), "--check"]) == 1
+    assert "dirr" in capsys.readouterr().out
