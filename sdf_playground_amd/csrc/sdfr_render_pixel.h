@@ -51,6 +51,21 @@ struct CachedRayStore
 	}
 };
 
+// Q1 of SURVEY.md 8: the reference takes the forward-difference normal of every hit, also of
+// shadow-ray hits, whose shading never looks at it -- unless the scene's material callback reads
+// MaterialInput.obj_normal.  A scene that declares `shadow_hits_need_normal = false` lets the
+// pixel kernel skip those three scene evaluations; outputs and counters are unchanged.  Scenes
+// without the declaration (run-time scenes by default) keep the reference's behaviour.
+template <class...>
+struct VoidOf { typedef void type; };
+template <class Scene, class = void>
+struct ShadowHitsNeedNormal { static constexpr bool value = true; };
+template <class Scene>
+struct ShadowHitsNeedNormal<Scene, typename VoidOf<decltype(Scene::shadow_hits_need_normal)>::type>
+{
+	static constexpr bool value = Scene::shadow_hits_need_normal;
+};
+
 struct PixelCounters
 {
 	uint32_t rays, march_evals, hits;
@@ -124,11 +139,15 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			hit.t = m.t;
 			hit.d = m.d;
 			hit.iter = m.iter;
-			const float baseline = m.d * inside_sign;
-			float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-			hit.normal = normalize(V3(g0, g1, g2));
+			hit.normal = V3s(0.f);
+			if (ShadowHitsNeedNormal<Scene>::value || !ray_is_shadow(ray))
+			{
+				const float baseline = m.d * inside_sign;
+				float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+				float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+				float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
+				hit.normal = normalize(V3(g0, g1, g2));
+			}
 #ifdef SDFR_PHASE_CLOCKS
 			asm volatile("" : "+v"(hit.normal.x), "+v"(hit.normal.y), "+v"(hit.normal.z));
 #endif

@@ -24,6 +24,7 @@ namespace sdfr {
 struct SceneFastSphere
 {
 	static const char *name() { return "fast_sphere"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
@@ -56,6 +57,7 @@ struct SceneFastSphere
 struct SceneCubeSea
 {
 	static const char *name() { return "cube_sea"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; vec2 barrier; };
@@ -121,6 +123,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_FIRE_SCROLL = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_FIRE_SCROLL] = U.stime * 3.f; }
@@ -258,6 +261,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
@@ -329,6 +333,7 @@ struct SceneFractal
 struct SceneLense
 {
 	static const char *name() { return "lense"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	// the scene's variable tags in source order; slot k of FrameU::scene_var is the k-th distinct name
 	static const char *variables()
 	{
@@ -442,6 +447,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
 	static SDF_HD void prepare(FrameU &U)
@@ -499,6 +505,7 @@ struct SceneGems
 struct SceneLightShadows
 {
 	static const char *name() { return "light_shadows"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	// su layout: 5 x {x, y_geometry, z, y_light} then 5 x rgb (colour of sphere i)
 	enum { SU_SPHERES = 0, SU_COLORS = 20 };

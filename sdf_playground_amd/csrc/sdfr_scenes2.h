@@ -11,6 +11,7 @@ namespace sdfr {
 struct SceneCube
 {
 	static const char *name() { return "cube"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	enum { V_SIZE = 0, V_X, V_Y, V_Z, V_RED, V_GREEN, V_BLUE };
 	static const char *variables()
 	{
@@ -55,6 +56,7 @@ struct SceneCube
 struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { int unused; };
@@ -88,6 +90,7 @@ struct SceneGyroid
 struct SceneBasicTransparency
 {
 	static const char *name() { return "basic_transparency"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	static SDF_HD float pane(vec3 p, float z) { return sd_box(p - V3(0.f, 2.f, z), V3(1.f, 1.f, 0.1f)); }
@@ -130,6 +133,7 @@ struct SceneBasicTransparency
 struct SceneBasicClouds
 {
 	static const char *name() { return "basic_clouds"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return "VAR_offset(min = -5, max = 5, step = 0.05)"; }
 	static SDF_HD void prepare(FrameU &) {}
 	static SDF_HD float slab(vec3 p) { return sd_box(p - V3(0.f, 5.f, 0.f), V3(2.f, 0.5f, 2.f)); }
@@ -241,6 +245,7 @@ struct SceneCoordinateMaterial
 struct SceneDistortion
 {
 	static const char *name() { return "distortion"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
@@ -302,6 +307,7 @@ struct SceneDistortion
 struct SceneTable
 {
 	static const char *name() { return "table"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
@@ -369,6 +375,7 @@ struct SceneTable
 struct SceneSierpinski
 {
 	static const char *name() { return "sierpinski"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
@@ -423,6 +430,7 @@ struct SceneSierpinski
 struct SceneNeon
 {
 	static const char *name() { return "neon"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables()
 	{
 		return "VAR_r1(min = 0.2, max = 2, start = 1) VAR_r2(min = 0.005, max = 0.1, start = 0.01) VAR_spacing(min = 0.01, max = 0.2, start = 0.1) "

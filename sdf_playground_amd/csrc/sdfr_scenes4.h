@@ -9,6 +9,7 @@ namespace sdfr {
 struct SceneTree
 {
 	static const char *name() { return "tree"; }
+	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_DRIFT = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
