@@ -382,15 +382,36 @@ struct SceneLense
 		o.frame = sd_box(mp, V3(1.1f, 2.1f, 0.08f));
 		return o;
 	}
+	// The mirror pane and its frame (two boxes, 45 of the 180 instructions of an evaluation) lie in
+	// the ball of radius 2.38 about (0, 0, -5), whatever the pane's rotation about its vertical
+	// axis; sd_box is an exact distance, so both are >= |p - c| - 2.38 and can be left out of the
+	// min() whenever that bound is not below the running minimum (0.01 of slack for rounding;
+	// checked numerically in tests/test_scene_bounds_cpu.py).
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool)
 	{
-		Objects o = eval_objects(U, p);
-		float d = min1(3e38f, o.bg1);
-		d = min1(d, o.bg2);
-		d = min1(d, o.lense);
-		d = min1(d, o.sphere);
-		d = min1(d, o.mirror);
-		return min1(d, o.frame);
+		vec3 b1 = p - V3(0.f, -5.f, 0.f);
+		vec2 r1 = op_rep_inf_c(V2(b1.x, b1.z), 3.f, 1.0f / 3.f);
+		float d = min1(3e38f, blob(V3(r1.x, b1.y, r1.y)));
+
+		vec3 b2 = p - V3(0.f, 5.f, 0.f);
+		vec2 r2 = op_rep_inf_c(V2(b2.x, b2.z), 10.f, 1.0f / 10.f);
+		d = min1(d, blob(V3(r2.x, b2.y, r2.y)));
+
+		vec3 lp = abs(p);
+		lp.z = lp.z - 5.1f;
+		d = min1(d, max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f)));
+		d = min1(d, sd_sphere(p - V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]), 2.f));
+
+		vec3 mp = p - V3(0.f, 0.f, -5.f);
+		const float k = max1(d, 0.f) + (2.38f + 0.01f);
+		if (!(dot(mp, mp) >= k * k))
+		{
+			vec2 mr = rot2(V2(mp.x, mp.z), U.su[SU_MIRROR_S], U.su[SU_MIRROR_C]);
+			mp = V3(mr.x, mp.y, mr.y);
+			d = min1(d, sd_box(mp, V3(1.f, 2.f, 0.1f)));
+			d = min1(d, sd_box(mp, V3(1.1f, 2.1f, 0.08f)));
+		}
+		return d;
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

@@ -107,3 +107,24 @@ extern "C" long long hostsim_check_labyrinth_bounds(long long n, unsigned seed)
 	}
 	return bad;
 }
+
+// the lense scene's bounding ball of mirror pane + frame (sdfr_scenes.h, SceneLense::dist)
+extern "C" long long hostsim_check_lense_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 777ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		const vec3 mp = V3(rnd() * 12.f - 6.f, rnd() * 12.f - 6.f, rnd() * 12.f - 6.f); // relative to (0, 0, -5)
+		const vec2 sc = sincos1(rnd() * 6.2831853f);
+		const vec2 mr = rot2(V2(mp.x, mp.z), sc.x, sc.y);
+		const vec3 q = V3(mr.x, mp.y, mr.y);
+		const float lb = length(mp) - 2.38f;
+		if (lb >= 0.f && (sd_box(q, V3(1.f, 2.f, 0.1f)) < lb - 1e-4f || sd_box(q, V3(1.1f, 2.1f, 0.08f)) < lb - 1e-4f)) ++bad;
+	}
+	return bad;
+}

@@ -31,3 +31,22 @@ def test_culling_is_invisible_near_vases_and_torches(oracle):
             img, st = hostsim.render("labyrinth", hostsim.frame_from_oracle(f))
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
             assert np.array_equal(st, rst)
+
+
+def test_lense_bounds_hold_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_lense_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_lense_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_lense_bounds(3000000, 11) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    # cameras close to the mirror pane (at (0, 0, -5)), through it and from the far side
+    for eye, at in [((2.5, 1.0, -2.5), (0.0, 0.0, -5.0)), ((-1.5, 2.5, -8.0), (0.0, 0.0, -5.0)), ((0.3, 0.2, -3.2), (0.0, 0.5, -5.0)),
+                    ((6.0, 0.5, 4.0), (0.0, 0.0, -5.0))]:
+        for stime in (0.0, 2.3):
+            f = oracle.default_frame("lense", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=stime)
+            ref, rst, _ = oracle.render("lense", f, stats=True)
+            img, st = hostsim.render("lense", hostsim.frame_from_oracle(f))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, stime)
+            assert np.array_equal(st, rst)
