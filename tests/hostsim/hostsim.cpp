@@ -128,3 +128,27 @@ extern "C" long long hostsim_check_lense_bounds(long long n, unsigned seed)
 	}
 	return bad;
 }
+
+// the fractal scene's bounding ball (sdfr_scenes.h, SceneFractal::dist)
+extern "C" long long hostsim_check_fractal_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 4242ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		// half of the samples close to the ball's surface, where a protruding box would show
+		const float r = (i & 1) ? 0.9f + rnd() * 0.4f : rnd() * 5.f;
+		vec3 v = V3(rnd() * 2.f - 1.f, rnd() * 2.f - 1.f, rnd() * 2.f - 1.f);
+		const float len = length(v);
+		if (len < 1e-3f) continue;
+		const vec3 p = V3(0.f, 1.f, 0.f) + v * (r / len);
+		float lvl;
+		const float d = SceneFractal::fold(p, &lvl);
+		if (d < (r - 1.f) - 1e-5f) ++bad;
+	}
+	return bad;
+}

@@ -50,3 +50,20 @@ def test_lense_bounds_hold_and_culling_is_invisible(oracle):
             img, st = hostsim.render("lense", hostsim.frame_from_oracle(f))
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, stime)
             assert np.array_equal(st, rst)
+
+
+def test_fractal_bound_holds_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_fractal_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_fractal_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_fractal_bounds(4000000, 5) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for eye, at in [((2.2, 1.6, 0.3), (0.0, 1.0, 0.0)), ((0.9, 1.9, 0.9), (0.0, 1.0, 0.0)), ((0.0, 3.5, 0.1), (0.0, 1.0, 0.0)), ((6.0, 0.4, 5.0), (0.0, 1.0, 0.0))]:
+        f = oracle.default_frame("fractal", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.0)
+        f.iter_count = 512
+        ref, rst, _ = oracle.render("fractal", f, stats=True)
+        img, st = hostsim.render("fractal", hostsim.frame_from_oracle(f))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+        assert np.array_equal(st, rst)
