@@ -152,3 +152,24 @@ extern "C" long long hostsim_check_fractal_bounds(long long n, unsigned seed)
 	}
 	return bad;
 }
+
+// the distortion scene's lower bound of the displaced wall (sdfr_scenes2.h)
+extern "C" long long hostsim_check_distortion_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 99ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		// a third of the samples hug the wall, a third are room-scale, a third far away
+		const float s = (i % 3 == 0) ? 0.3f : ((i % 3 == 1) ? 6.f : 3000.f);
+		const vec3 p = V3(0.f, 1.5f, 0.f) + V3((rnd() * 2.f - 1.f) * (1.f + s), (rnd() * 2.f - 1.f) * (1.f + s), (rnd() * 2.f - 1.f) * (0.1f + s));
+		bool valid;
+		const float lb = SceneDistortion::wall_lower_bound(p, &valid);
+		if (valid && SceneDistortion::wall(p).box < lb) ++bad;
+	}
+	return bad;
+}

@@ -67,3 +67,19 @@ def test_fractal_bound_holds_and_culling_is_invisible(oracle):
         img, st = hostsim.render("fractal", hostsim.frame_from_oracle(f))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
         assert np.array_equal(st, rst)
+
+
+def test_distortion_bound_holds_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_distortion_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_distortion_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_distortion_bounds(600000, 3) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for eye, at in [((0.8, 1.8, -2.5), (0.0, 1.5, 0.0)), ((0.2, 1.5, -0.35), (0.0, 1.5, 0.0)), ((2.5, 0.3, 0.02), (0.0, 1.5, 0.0)), ((-3.0, 4.0, 3.0), (0.0, 1.0, 0.0))]:
+        f = oracle.default_frame("distortion", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.4)
+        ref, rst, _ = oracle.render("distortion", f, stats=True)
+        img, st = hostsim.render("distortion", hostsim.frame_from_oracle(f))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+        assert np.array_equal(st, rst)
