@@ -50,10 +50,13 @@ struct SceneTree
 
 		for (uint i = 0; i < iters; ++i)
 		{
-			real branch = sdBranch(pos / tree_scale, real(1.f), real(0.1f), real(0.05f)) * tree_scale;
+			// same quotients as pos / tree_scale; r_div_const additionally records, in the census build,
+			// numerators outside the domain on which the kernels' constant division is proven exact
+			const float3 scaled_pos = float3(r_div_const(pos.x, tree_scale), r_div_const(pos.y, tree_scale), r_div_const(pos.z, tree_scale));
+			real branch = sdBranch(scaled_pos, real(1.f), real(0.1f), real(0.05f)) * tree_scale;
 			tree = smin(tree, branch, real(0.01f));
 
-			real leaf = sdSphere(pos / tree_scale - float3(real(0.f), real(1.f) + sphere_size * leaf_scale, real(0.f)), sphere_size * leaf_scale) * tree_scale;
+			real leaf = sdSphere(scaled_pos - float3(real(0.f), real(1.f) + sphere_size * leaf_scale, real(0.f)), sphere_size * leaf_scale) * tree_scale;
 			leafes = r_min(leafes, leaf);
 
 			real height = (i == 0) ? height_offset1 : height_offset2;

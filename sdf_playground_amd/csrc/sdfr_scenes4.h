@@ -42,8 +42,12 @@ struct SceneTree
 #pragma unroll
 		for (int i = 0; i < 9; ++i)
 		{
-			t = op_smin(t, branch(p / tree_scale, 1.f, 0.1f, 0.05f) * tree_scale, 0.01f);
-			l = min1(l, sd_sphere(p / tree_scale - V3(0.f, 1.f + ball * leaf_scale, 0.f), ball * leaf_scale) * tree_scale);
+			// tree_scale = 1.4^-i is a compile-time constant after unrolling: the division is a div_c
+			// (exact for all nine constants: tests/test_gpu_math.py, SCENE_DIVISORS)
+			const float inv_scale = 1.0f / tree_scale;
+			const vec3 ps = V3(div_c(p.x, tree_scale, inv_scale), div_c(p.y, tree_scale, inv_scale), div_c(p.z, tree_scale, inv_scale));
+			t = op_smin(t, branch(ps, 1.f, 0.1f, 0.05f) * tree_scale, 0.01f);
+			l = min1(l, sd_sphere(ps - V3(0.f, 1.f + ball * leaf_scale, 0.f), ball * leaf_scale) * tree_scale);
 
 			const float height = i == 0 ? height0 : 0.41f;
 			p.y = p.y - height * tree_scale;

@@ -16,6 +16,11 @@ SCENE_DIVISORS = [
     15.0,                                              # turbulence3 normalisation
     float(np.float32(np.float32(np.float32(1.41421356237309504) * np.float32(0.1)) / np.float32(4.0))),  # op_pipe period (labyrinth vase)
 ]
+# tree: the branch generations' scales 1.4^-i, formed like the scene does (repeated fp32 division)
+_scale = np.float32(1.0)
+for _i in range(8):
+    _scale = np.float32(_scale / np.float32(1.4))
+    SCENE_DIVISORS.append(float(_scale))
 
 
 @pytest.fixture(scope="module")
