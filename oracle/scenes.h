@@ -245,7 +245,9 @@ struct SceneFractal
 
 		for (int i = 0; i < 8; ++i)
 		{
-			real new_d = sdBox(fractal_pos, size * real(0.5f)) / scale;
+			// r_div_const: same quotient; the census build also records numerators outside the domain on
+			// which the kernels' constant division (by 3^i) is proven exact
+			real new_d = r_div_const(sdBox(fractal_pos, size * real(0.5f)), scale);
 			if (new_d < real(0.0001f) && fractal > real(0.0001f))
 			{
 				iters_needed = real((float)i);

@@ -290,7 +290,9 @@ struct SceneFractal
 #pragma unroll
 		for (int i = 0; i < 8; ++i)
 		{
-			float nd = sd_box(q, V3s(size * 0.5f)) / scale;
+			// scale = 3^i is a compile-time constant after unrolling: div_c is exact for all of them
+			// (tests/test_gpu_math.py, SCENE_DIVISORS)
+			float nd = div_c(sd_box(q, V3s(size * 0.5f)), scale, 1.0f / scale);
 			if (nd < 0.0001f && d > 0.0001f) hit_level = (float)i;
 			d = min1(d, nd);
 			q = abs(q);
