@@ -57,11 +57,25 @@ inline void census_check_plane(float a, float c)
 		if (getenv("ORC_CENSUS_VERBOSE")) fprintf(stderr, "plane out of domain: height %a (%g) denom %a\n", a, a, c);
 	}
 }
+// division by a ray-direction component through a per-ray reciprocal (cube_sea's cell guard in the
+// kernels): exact for numerators 0 or 2^-60..2^40 whenever the kernels take that route (|den| >= 2^-60)
+inline void census_check_raydiv(float a, float c)
+{
+	if (!(fabsf(c) >= 0x1p-60f)) return; // the kernels keep the IEEE division here
+	float m = fabsf(a);
+	if (a != a || m > 0x1p40f) census().far_field++;
+	else if (!(m == 0.f || m >= 0x1p-60f))
+	{
+		census().divc_out_of_domain++;
+		if (getenv("ORC_CENSUS_VERBOSE")) fprintf(stderr, "ray division out of domain: numerator %a (%g) den %a\n", a, a, c);
+	}
+}
 #define ORC_COUNT(n) (census().flops += (n))
 #define ORC_COUNT_T() (census().flops += 1, census().transc += 1)
 #define ORC_CHECK_SQRT(a) census_check_sqrt(a)
 #define ORC_CHECK_DIVC(a) census_check_divc(a)
 #define ORC_CHECK_PLANE(a, c) census_check_plane(a, c)
+#define ORC_CHECK_RAYDIV(a, c) census_check_raydiv(a, c)
 struct real
 {
 	float v;
@@ -94,6 +108,7 @@ inline float val(real a) { return a; }
 #define ORC_CHECK_SQRT(a) ((void)0)
 #define ORC_CHECK_DIVC(a) ((void)0)
 #define ORC_CHECK_PLANE(a, c) ((void)0)
+#define ORC_CHECK_RAYDIV(a, c) ((void)0)
 #endif
 
 typedef unsigned int uint;

@@ -248,6 +248,8 @@ inline real sdLimit2(float2 pos, float2 dir, float2 lim_val)
 {
 	float2 barrier_to_use = v_step(real(0.f), dir) - real(0.5f);
 	float2 barrier_pos = barrier_to_use * lim_val - pos;
+	ORC_CHECK_RAYDIV(val(barrier_pos.x), val(dir.x));
+	ORC_CHECK_RAYDIV(val(barrier_pos.y), val(dir.y));
 	float2 t = barrier_pos / dir;
 	return r_min(t.x, t.y);
 }

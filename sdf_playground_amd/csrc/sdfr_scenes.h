@@ -60,14 +60,28 @@ struct SceneCubeSea
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
-	struct RayInv { GroundInv ground; vec2 barrier; };
+	// The cell-wall guard divides by the ray direction's x and z at every step: per ray, their
+	// reciprocals are formed once (IEEE) and the steps use div_c, which is the correctly rounded
+	// quotient for numerators 0 or 2^-60 <= |a| <= 2^40 (the wall offsets are multiples of 2^-24
+	// below 2.1) and, as far as 250 000 random divisors in [2^-66, 2] times every numerator can
+	// tell, any divisor (tools/divsweep_long.py; the ground plane relies on the same fact).
+	// Directions closer to an axis than 2^-60, and exact zeros, keep the IEEE division.
+	struct RayInv { GroundInv ground; vec2 barrier; vec2 rdir; bool exact_x, exact_z; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
 		// cell-wall guard (sdf_primitives.hlsl:118-124): which wall the ray runs towards
 		r.barrier = (V2(step1(0.f, dir.x), step1(0.f, dir.z)) - 0.5f) * V2(2.01f, 2.01f);
+		r.exact_x = abs1(dir.x) >= 8.6736174e-19f; // 2^-60
+		r.exact_z = abs1(dir.z) >= 8.6736174e-19f;
+		r.rdir = V2(r.exact_x ? 1.0f / dir.x : 0.f, r.exact_z ? 1.0f / dir.z : 0.f);
 		return r;
+	}
+	static SDF_HD float guard_quotient(float num, float den, float rden, bool exact)
+	{
+		if (exact) return div_c(num, den, rden);
+		return num / den;
 	}
 	struct Cell { vec3 cell_pos; float cube; bool is_other; };
 	static SDF_HD Cell eval_cell(const FrameU &U, vec3 p)
@@ -92,8 +106,10 @@ struct SceneCubeSea
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		Cell c = eval_cell(U, p);
 		d = min1(d, c.cube);
-		vec2 t = (R.barrier - V2(c.cell_pos.x, c.cell_pos.z)) / V2(dir.x, dir.z);
-		return min1(d, min1(t.x, t.y));
+		const vec2 num = R.barrier - V2(c.cell_pos.x, c.cell_pos.z);
+		const float tx = guard_quotient(num.x, dir.x, R.rdir.x, R.exact_x);
+		const float tz = guard_quotient(num.y, dir.z, R.rdir.y, R.exact_z);
+		return min1(d, min1(tx, tz));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
