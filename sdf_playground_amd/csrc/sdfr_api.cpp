@@ -626,7 +626,7 @@ int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_
 
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches)
 {
-	if (!r || !mismatches || what < 0 || what > 3) return SDFR_ERR_INVALID_ARGUMENT;
+	if (!r || !mismatches || what < 0 || what > 5) return SDFR_ERR_INVALID_ARGUMENT;
 	if (what >= 1 && !(constant != 0.f && constant == constant)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad divisor");
 	SDFR_HIP(hipSetDevice(r->device));
 	unsigned long long *d = nullptr;

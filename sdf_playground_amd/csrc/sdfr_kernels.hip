@@ -426,6 +426,15 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_selftest_math(int what, float c,
 			ref = sqrt_ieee(a);
 			got = sqrt1(a);
 		}
+		else if (what == 4 || what == 5)
+		{
+			// what = 4: rcp1(a) against the IEEE 1 / a for a = +-0, +-inf and 2^-100 <= |a| <= 2^100
+			// what = 5: negative control -- the bare v_rcp_f32 (1 ulp) on the same inputs (must differ)
+			const float m = abs1(a);
+			if (!(m == 0.f) && !(m >= 0x1p-100f && m <= 0x1p100f) && !(m > 3.402823466e+38f)) continue;
+			ref = 1.0f / a;
+			got = what == 4 ? rcp1(a) : __builtin_amdgcn_rcpf(a);
+		}
 		else
 		{
 			const float m = abs1(a);

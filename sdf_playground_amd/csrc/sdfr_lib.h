@@ -87,7 +87,7 @@ SDF_HD float sd_round_cone(vec3 p, vec3 a, vec3 b, float r1, float r2)
 	float l2 = dot(ba, ba);
 	float rr = r1 - r2;
 	float a2 = l2 - rr * rr;
-	float il2 = 1.0f / l2;
+	float il2 = rcp1(l2);
 
 	vec3 pa = p - a;
 	float y = dot(pa, ba);
@@ -415,7 +415,7 @@ SDF_HD GroundInv ground_setup(vec3 dir)
 {
 	GroundInv g;
 	g.denom = sat1(dot(dir, -V3(0.f, 1.f, 0.f))) + 1e-20f;
-	g.rdenom = 1.0f / g.denom;
+	g.rdenom = rcp1(g.denom);
 	return g;
 }
 SDF_HD float ground_dist(vec3 p, bool fast, const GroundInv &g)

@@ -117,7 +117,21 @@ SDF_HD float sqrt1(float a)
 }
 // the generic lowering, valid for every input (reference for the self-test)
 SDF_HD float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
-SDF_HD float rsqrt1(float a) { return 1.0f / sqrt1(a); }
+// 1 / a as v_rcp_f32 plus one Newton step: y = rcp(a); y' = fma(fma(-a, y, 1), y, y) -- 3
+// instructions (+ a class test and a select for a = 0 or inf, which keep rcp's own result) instead
+// of the ~10 of the IEEE divide.  Exhaustively compared on gfx950 with 1.0f / a: bit-identical
+// for a = +-0, +-inf and EVERY 2^-100 <= |a| <= 2^100 (sdfr_selftest_math what = 4).
+SDF_HD float rcp1(float a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const float y = __builtin_amdgcn_rcpf(a);
+	const float r = __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
+	return __builtin_amdgcn_class(a, 0x260 | 0x204) ? y : r; // +-0 (0x60) and +-inf (0x204): rcp is exact there
+#else
+	return 1.0f / a;
+#endif
+}
+SDF_HD float rsqrt1(float a) { return rcp1(sqrt1(a)); }
 
 // a / c for a constant c, rc = 1.0f / c folded at compile time:
 //     q = a*rc; t = fma(c, q, -a); q' = fma(-t, rc, q)       (= q + (a - c*q)*rc; written so
@@ -221,7 +235,7 @@ SDF_HD vec2 sincos1(float x)
 SDF_HD float atan_nonneg(float t)
 {
 	float y = 0.f;
-	if (t > 2.414213562373095f) { y = 1.57079632679489661923f; t = -(1.0f / t); }
+	if (t > 2.414213562373095f) { y = 1.57079632679489661923f; t = -rcp1(t); }
 	else if (t > 0.4142135623730950f) { y = 0.78539816339744830962f; t = (t - 1.0f) / (t + 1.0f); }
 	float z = t * t;
 	float p = fma1(8.05374449538e-2f, z, -1.38776856032e-1f);

@@ -25,7 +25,7 @@ SDF_HD PixelRay pixel_ray(const FrameU &U, int px, int py)
 	float sx = ((float)px + 0.5f) / (float)U.width * 2.f - 1.f;
 	float sy = 1.f - ((float)py + 0.5f) / (float)U.height * 2.f;
 	vec3 d = U.front + sx * U.right + sy * U.top;
-	float invlen = 1.f / length(d);
+	float invlen = rcp1(length(d));
 	PixelRay r;
 	r.dir = d * invlen;
 	r.right_ray = U.ddx * U.right * invlen;

@@ -75,7 +75,7 @@ struct SceneCubeSea
 		r.barrier = (V2(step1(0.f, dir.x), step1(0.f, dir.z)) - 0.5f) * V2(2.01f, 2.01f);
 		r.exact_x = abs1(dir.x) >= 8.6736174e-19f; // 2^-60
 		r.exact_z = abs1(dir.z) >= 8.6736174e-19f;
-		r.rdir = V2(r.exact_x ? 1.0f / dir.x : 0.f, r.exact_z ? 1.0f / dir.z : 0.f);
+		r.rdir = V2(r.exact_x ? rcp1(dir.x) : 0.f, r.exact_z ? rcp1(dir.z) : 0.f);
 		return r;
 	}
 	static SDF_HD float guard_quotient(float num, float den, float rden, bool exact)

@@ -54,6 +54,12 @@ def test_fast_ground_plane_division_is_exact(renderer):
         assert renderer.selftestMath(3, float(c)) == 0, float(c)
 
 
+def test_fast_reciprocal_is_exact(renderer):
+    """rcp1 = v_rcp_f32 + one Newton step: the IEEE 1 / a for +-0, +-inf and every 2^-100 <= |a| <= 2^100."""
+    assert renderer.selftestMath(4) == 0
+    assert renderer.selftestMath(5) > 0      # negative control: the bare hardware reciprocal is not
+
+
 def test_selftest_is_not_vacuous(renderer):
     # negative control: the plain reciprocal multiply is NOT the correctly rounded quotient
     assert renderer.selftestMath(2, 3.0) > 0
