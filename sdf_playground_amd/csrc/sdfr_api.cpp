@@ -112,7 +112,7 @@ static int ensure_workspace(sdfr_renderer *r, size_t pixels, bool wavefront)
 		auto alloc = [&](void **p, size_t bytes) {
 			if (e == hipSuccess && *p == nullptr) e = hipMalloc(p, bytes);
 		};
-		alloc((void **)&w.ray_queue, sizeof(float) * 11 * SDFR_MAX_RAYS * n);
+		alloc((void **)&w.ray_queue, sizeof(float) * 12 * SDFR_MAX_RAYS * n); // 48-byte records (pixel schedule) / 11 field arrays (wavefront)
 		alloc((void **)&w.partials, sizeof(RenderTotals) * (n / 64 + 1));
 		if (wavefront)
 		{

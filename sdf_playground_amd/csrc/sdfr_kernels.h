@@ -12,7 +12,7 @@ struct WavefrontWorkspace
 {
 	size_t capacity;     // pixels
 	float *ray_cur;      // [11][capacity] ray being traced for each pixel
-	float *ray_queue;    // [8][11][capacity] pending rays
+	float *ray_queue;    // [8][capacity] pending rays, 48-byte records (GlobalRayStore)
 	uint32_t *qdepth_lo; // [capacity] packed depths of slots 0-3
 	uint32_t *qdepth_hi; // [capacity] packed depths of slots 4-7
 	float *result;       // [8][capacity] march result: status/iter, t, d, normal xyz (+2 spare)

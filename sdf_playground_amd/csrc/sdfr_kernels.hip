@@ -315,6 +315,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 			float hdr = ws.accum[3 * cap + pid];
 
 			vec3 add;
+			GlobalRayStore store = {ws.ray_queue, cap, pid}; // the pixel's pending rays (48-byte records)
 			if (status == MARCH_HIT)
 			{
 				HitInfo hit;
@@ -324,7 +325,6 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 				hit.normal = V3(ws.result[RS_NX * cap + pid], ws.result[RS_NY * cap + pid], ws.result[RS_NZ * cap + pid]);
 				hit.pos = mad(ray.dir, hit.t, ray.pos);
 				const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
-				GlobalRayStore store = {ws.ray_queue, cap, pid};
 				Spawner<GlobalRayStore> q(store, depths, count, U.ray_count);
 				add = shade_hit<Scene, DBG, GlobalRayStore>(U, F, ray, pr, hit, max_range, hdr, q);
 				depths = q.depths;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 			{
 				// pop the pixel's next ray: it is traced in the next round
 				const int slot = queue_next(depths, U.ray_count);
-				const RayRec nr = load_ray(ws.ray_queue + (size_t)slot * RF_COUNT * cap, cap, pid);
+				const RayRec nr = store.get(slot);
 				store_ray(ws.ray_cur, cap, pid, nr);
 				depths = queue_set_depth(depths, slot, RAY_DEPTH_INVALID);
 				ws.qdepth_lo[pid] = (uint32_t)depths;

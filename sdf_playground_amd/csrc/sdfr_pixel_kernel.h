@@ -161,15 +161,37 @@ __device__ __forceinline__ void store_ray(float *base, size_t cap, uint32_t pid,
 	base[RF_BITS * cap + pid] = __uint_as_float(r.bits);
 }
 
-// pending rays of one pixel in the HBM queue arrays: [slot][field][pixel], so that lanes
-// holding neighbouring pixels touch neighbouring addresses
+// Pending rays of one pixel in HBM, pixel schedule: one 48-byte record per (slot, pixel) -- three
+// 16-byte accesses off ONE address.  (The wavefront kernels keep their queue as structure-of-
+// arrays, load_ray / store_ray above, because there a wave reads the same field of consecutive
+// pixels; here almost every ray stays in the LDS cache, and per-field arrays cost eleven 64-bit
+// addresses that the compiler forms in the prologue and spills.)  Both layouts use the same
+// workspace buffer, never within one frame.
 struct GlobalRayStore
 {
 	float *queue;
 	size_t cap;
 	uint32_t pid;
-	__device__ __forceinline__ void put(int slot, const RayRec &r) { store_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid, r); }
-	__device__ __forceinline__ RayRec get(int slot) const { return load_ray(queue + (size_t)slot * RF_COUNT * cap, cap, pid); }
+	__device__ __forceinline__ float4 *record(int slot) const { return reinterpret_cast<float4 *>(queue) + ((size_t)slot * cap + pid) * 3; }
+	__device__ __forceinline__ void put(int slot, const RayRec &r)
+	{
+		float4 *rec = record(slot);
+		rec[0] = make_float4(r.pos.x, r.pos.y, r.pos.z, r.dir.x);
+		rec[1] = make_float4(r.dir.y, r.dir.z, r.contrib.x, r.contrib.y);
+		rec[2] = make_float4(r.contrib.z, r.shadow_range, __uint_as_float(r.bits), 0.f);
+	}
+	__device__ __forceinline__ RayRec get(int slot) const
+	{
+		const float4 *rec = record(slot);
+		const float4 a = rec[0], b = rec[1], c = rec[2];
+		RayRec r;
+		r.pos = V3(a.x, a.y, a.z);
+		r.dir = V3(a.w, b.x, b.y);
+		r.contrib = V3(b.z, b.w, c.x);
+		r.shadow_range = c.y;
+		r.bits = __float_as_uint(c.z);
+		return r;
+	}
 };
 
 // The pixel kernel's ray store: the write-behind cache of CachedRayStore and the pixel's ray
