@@ -402,6 +402,15 @@ SDF_HD float mat_coordinate_grid(vec3 p, vec3 n, float width)
 	return dot(tick, mask);
 }
 
+// order (a, b, c) so that a >= b >= c, as three compare-exchanges (the fractal scenes' fold)
+SDF_HD void sort3_desc(float &a, float &b, float &c)
+{
+	float t;
+	if (c > b) { t = b; b = c; c = t; }
+	if (b > a) { t = a; a = b; b = t; }
+	if (c > b) { t = b; b = c; c = t; }
+}
+
 // ---- helpers every scene shares: checker floor, the standard sun (sdf_common.hlsl:62-94) ------
 // needs SurfacePoint / Material / Light
 // Ray-dependent part of the shared checker floor (sdf_common.hlsl:62-83 via

@@ -287,14 +287,6 @@ struct SceneFractal
 		r.ground = ground_setup(dir);
 		return r;
 	}
-	// order (a, b, c) so that a >= b >= c, as three compare-exchanges
-	static SDF_HD void sort3_desc(float &a, float &b, float &c)
-	{
-		float t;
-		if (c > b) { t = b; b = c; c = t; }
-		if (b > a) { t = a; a = b; b = t; }
-		if (c > b) { t = b; b = c; c = t; }
-	}
 	// 8-level recursive fold; returns the distance, and the level that first touched
 	static SDF_HD float fold(vec3 p, float *level_hit)
 	{

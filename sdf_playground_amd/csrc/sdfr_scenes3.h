@@ -30,11 +30,11 @@ struct SceneFractal2
 		{
 			d = min1(d, sd_box(q, V3s(size * 0.5f)) / scale);
 			q = abs(q);
-			SceneFractal::sort3_desc(q.y, q.x, q.z);
+			sort3_desc(q.y, q.x, q.z);
 			q.y = q.y - size * 2.f / 3.f;
 			q.z = q.z - step1(size * 0.5f / 3.f, q.z) * size / 3.f * 1.001f;
 			q.y = q.y + size / 3.f;
-			SceneFractal::sort3_desc(q.y, q.x, q.z);
+			sort3_desc(q.y, q.x, q.z);
 			q.y = q.y - size / 3.f;
 			q = q * 3.f;
 			scale = scale * 3.f;
