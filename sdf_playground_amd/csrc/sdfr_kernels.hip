@@ -372,36 +372,33 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 }
 
 // ---- strip assembly on the root (multi-GPU) ---------------------------------------------------------
-// gathered[rank][local pixel] -> image[global pixel]; RGBA32F / RGBA16F strips copy 4 or 2 words per
-// pixel; packed strips (12-byte rgb triples, then one flag byte per pixel, per rank) expand to RGBA32F
+// gathered[rank][local pixel] -> image[global pixel].  One block row per image row (blockIdx.y), so
+// the strip arithmetic is wave-uniform and there is no per-pixel division; one 16-byte store per
+// pixel.  RGBA32F / RGBA16F strips are copied; packed strips (12-byte rgb triples, then one flag
+// byte per pixel, per rank) expand to RGBA32F.
 __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, int world, size_t strip_pixels, const uint32_t *gathered,
 	uint32_t *image, int format)
 {
-	const size_t total = (size_t)width * (size_t)height;
-	const size_t packed_rank_bytes = (13 * strip_pixels + 3) & ~(size_t)3;
-	for (size_t g = (size_t)blockIdx.x * SDFR_BLOCK + threadIdx.x; g < total; g += (size_t)gridDim.x * SDFR_BLOCK)
+	const uint32_t px = blockIdx.x * SDFR_BLOCK + threadIdx.x, py = blockIdx.y;
+	if (px >= (uint32_t)width) return;
+	const uint32_t strip = py >> 3;
+	const uint32_t rank = strip % (uint32_t)world, local_strip = strip / (uint32_t)world;
+	const size_t lpix = ((size_t)local_strip * 8u + (py & 7u)) * (size_t)width + px;
+	const size_t g = (size_t)py * (size_t)width + px;
+	if (format == FORMAT_STRIP_RGB32F_A8)
 	{
-		const uint32_t py = (uint32_t)(g / (size_t)width), px = (uint32_t)(g - (size_t)py * width);
-		const uint32_t strip = py >> 3;
-		const uint32_t rank = strip % (uint32_t)world, local_strip = strip / (uint32_t)world;
-		const size_t lrow = (size_t)local_strip * 8u + (py & 7u);
-		const size_t lpix = lrow * (size_t)width + px;
-		if (format == FORMAT_STRIP_RGB32F_A8)
-		{
-			const unsigned char *base = reinterpret_cast<const unsigned char *>(gathered) + (size_t)rank * packed_rank_bytes;
-			const uint32_t *rgb = reinterpret_cast<const uint32_t *>(base) + 3 * lpix;
-			image[g * 4 + 0] = rgb[0];
-			image[g * 4 + 1] = rgb[1];
-			image[g * 4 + 2] = rgb[2];
-			image[g * 4 + 3] = base[12 * strip_pixels + lpix] ? 0x3f800000u : 0u;
-		}
-		else
-		{
-			const int words_per_pixel = format == FORMAT_RGBA32F ? 4 : 2;
-			const size_t src = (size_t)rank * strip_pixels + lpix;
-			for (int k = 0; k < words_per_pixel; ++k)
-				image[g * words_per_pixel + k] = gathered[src * words_per_pixel + k];
-		}
+		const size_t packed_rank_bytes = (13 * strip_pixels + 3) & ~(size_t)3;
+		const unsigned char *base = reinterpret_cast<const unsigned char *>(gathered) + (size_t)rank * packed_rank_bytes;
+		const uint32_t *rgb = reinterpret_cast<const uint32_t *>(base) + 3 * lpix;
+		reinterpret_cast<uint4 *>(image)[g] = make_uint4(rgb[0], rgb[1], rgb[2], base[12 * strip_pixels + lpix] ? 0x3f800000u : 0u);
+	}
+	else if (format == FORMAT_RGBA32F)
+	{
+		reinterpret_cast<uint4 *>(image)[g] = reinterpret_cast<const uint4 *>(gathered)[(size_t)rank * strip_pixels + lpix];
+	}
+	else
+	{
+		reinterpret_cast<uint2 *>(image)[g] = reinterpret_cast<const uint2 *>(gathered)[(size_t)rank * strip_pixels + lpix];
 	}
 }
 
@@ -559,10 +556,7 @@ hipError_t launch_assemble_strips(int width, int height, int world, const void *
 {
 	const size_t strips = ((size_t)height + 7) / 8;
 	const size_t strip_pixels = ((strips + world - 1) / world) * 8 * (size_t)width;
-	const size_t total = (size_t)width * height;
-	uint32_t blocks = (uint32_t)((total + SDFR_BLOCK - 1) / SDFR_BLOCK);
-	if (blocks > 8192) blocks = 8192;
-	hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(SDFR_BLOCK), 0, stream, width, height, world, strip_pixels,
+	hipLaunchKernelGGL(k_assemble, dim3((width + SDFR_BLOCK - 1) / SDFR_BLOCK, height), dim3(SDFR_BLOCK), 0, stream, width, height, world, strip_pixels,
 		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), format);
 	return hipGetLastError();
 }
