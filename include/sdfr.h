@@ -145,6 +145,17 @@ int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, 
 #define SDFR_STRIP_ROWS 8
 int64_t sdfr_strip_buffer_pixels(int width, int height, int world);
 int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format); /* bytes of one rank's compact buffer */
+/* Unequal shares: the root's own pixels never cross a link, so when the links into the root bound the
+ * frame rate the root should render more than 1 / world of it.  Of every `priv_period` consecutive
+ * strips the first `priv_count` (0 <= priv_count < priv_period; 0 = off, the default) are PRIVATE
+ * to the root, which renders them straight into the final image with sdfr_render_private_strips;
+ * only the others are dealt round-robin, rendered into compact buffers and gathered.  Set the same
+ * split on every rank's handle; it applies to sdfr_render_strips and sdfr_assemble_strips
+ * (assembly leaves the private rows alone).  The _split variants size the compact buffers. */
+int sdfr_set_strip_split(sdfr_renderer *r, int priv_count, int priv_period);
+int64_t sdfr_strip_buffer_pixels_split(int width, int height, int world, int priv_count, int priv_period);
+int64_t sdfr_strip_buffer_bytes_split(int width, int height, int world, int format, int priv_count, int priv_period);
+int sdfr_render_private_strips(sdfr_renderer *r, int width, int height, void *out_image, int format);
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format);
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format);
 

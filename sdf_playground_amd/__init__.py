@@ -71,6 +71,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
     "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
+    "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
 ]
 
 _lib = None
@@ -130,6 +131,12 @@ def load_library():
     L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
     L.sdfr_strip_buffer_bytes.argtypes = [ci, ci, ci, ci]
     L.sdfr_strip_buffer_bytes.restype = ctypes.c_int64
+    L.sdfr_set_strip_split.argtypes = [vp, ci, ci]
+    L.sdfr_strip_buffer_pixels_split.argtypes = [ci, ci, ci, ci, ci]
+    L.sdfr_strip_buffer_pixels_split.restype = ctypes.c_int64
+    L.sdfr_strip_buffer_bytes_split.argtypes = [ci, ci, ci, ci, ci, ci]
+    L.sdfr_strip_buffer_bytes_split.restype = ctypes.c_int64
+    L.sdfr_render_private_strips.argtypes = [vp, ci, ci, vp, ci]
     L.sdfr_render.argtypes = [vp, ci, ci, vp, ci, ci, vp]
     L.sdfr_render_strips.argtypes = [vp, ci, ci, ci, ci, vp, ci]
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
@@ -157,13 +164,14 @@ def check_scene_source(source, arch="gfx950"):
     return rc == SDFR_OK, log.value.decode(errors="replace")
 
 
-def strip_buffer_pixels(width, height, world):
-    return int(load_library().sdfr_strip_buffer_pixels(width, height, world))
+def strip_buffer_pixels(width, height, world, split=(0, 1)):
+    return int(load_library().sdfr_strip_buffer_pixels_split(width, height, world, split[0], split[1]))
 
 
-def strip_buffer_bytes(width, height, world, fmt):
-    """Bytes of one rank's compact strip buffer in format `fmt` (RGBA32F, RGBA16F or STRIP_RGB32F_A8)."""
-    return int(load_library().sdfr_strip_buffer_bytes(width, height, world, fmt))
+def strip_buffer_bytes(width, height, world, fmt, split=(0, 1)):
+    """Bytes of one rank's compact strip buffer in format `fmt` (RGBA32F, RGBA16F or STRIP_RGB32F_A8);
+    split = (priv_count, priv_period) of setStripSplit."""
+    return int(load_library().sdfr_strip_buffer_bytes_split(width, height, world, fmt, split[0], split[1]))
 
 
 def _f3(v):
@@ -372,9 +380,22 @@ class SDFRenderer:
                                         st.ctypes.data_as(ctypes.c_void_p) if pixel_stats else None))
         return (img, st) if pixel_stats else img
 
+    def setStripSplit(self, priv_count, priv_period):
+        """Of every priv_period strips the first priv_count are private to the root (renderPrivateStrips),
+        the others are shared round-robin (renderStrips / assembleStrips).  (0, 1) = plain round-robin."""
+        self._check(self._L.sdfr_set_strip_split(self._h, int(priv_count), int(priv_period)))
+        self._split = (int(priv_count), int(priv_period))
+
+    def renderPrivateStrips(self, width, height, out, fmt=RGBA32F):
+        """Root only: render the private strips straight into the full-size device image `out`."""
+        assert out.is_cuda and out.is_contiguous() and out.numel() == width * height * 4
+        self._check(self._L.sdfr_render_private_strips(self._h, width, height, ctypes.c_void_p(out.data_ptr()), fmt))
+        return out
+
     def renderStrips(self, width, height, rank, world, out, fmt=RGBA32F):
         """Multi-GPU: render this rank's 8-row strips into the compact device tensor `out`."""
-        assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() == strip_buffer_bytes(width, height, world, fmt)
+        assert out.is_cuda and out.is_contiguous()
+        assert out.numel() * out.element_size() == strip_buffer_bytes(width, height, world, fmt, getattr(self, "_split", (0, 1)))
         self._check(self._L.sdfr_render_strips(self._h, width, height, rank, world, ctypes.c_void_p(out.data_ptr()), fmt))
         return out
 
@@ -445,18 +466,28 @@ class HDR:
         return self._r.postprocess(src, self._bloom, self._ldr)
 
 
-def assemble_strips_host(width, height, world, gathered):
+def _shared_index(strip, split):
+    """Index of a frame strip among the shared strips, or None if it is private (split = (m, M))."""
+    m, M = split
+    if m == 0:
+        return strip
+    j = strip % M
+    return None if j < m else (strip // M) * (M - m) + (j - m)
+
+
+def assemble_strips_host(width, height, world, gathered, split=(0, 1), image=None):
     """Host (numpy) statement of the strip layout: gathered[world, strip_buffer_pixels, C] ->
-    image[height, width, C].  Used by the CPU tests of the multi-rank path; the GPU path is
-    sdfr_assemble_strips."""
+    image[height, width, C] (private strips of `split` are left as they are in `image`).  Used by
+    the CPU tests of the multi-rank path; the GPU path is sdfr_assemble_strips."""
     gathered = np.asarray(gathered)
     C = gathered.shape[-1]
-    per_rank_rows = strip_buffer_pixels_host(width, height, world) // width
+    per_rank_rows = strip_buffer_pixels_host(width, height, world, split) // width
     g = gathered.reshape(world, per_rank_rows, width, C)
-    img = np.zeros((height, width, C), gathered.dtype)
+    img = np.zeros((height, width, C), gathered.dtype) if image is None else image
     for py in range(height):
-        strip = py // STRIP_ROWS
-        img[py] = g[strip % world, (strip // world) * STRIP_ROWS + py % STRIP_ROWS]
+        t = _shared_index(py // STRIP_ROWS, split)
+        if t is not None:
+            img[py] = g[t % world, (t // world) * STRIP_ROWS + py % STRIP_ROWS]
     return img
 
 
@@ -480,16 +511,25 @@ def unpack_strip_host(packed, n):
     return c
 
 
-def strip_buffer_pixels_host(width, height, world):
+def strip_buffer_pixels_host(width, height, world, split=(0, 1)):
     strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
-    return ((strips + world - 1) // world) * STRIP_ROWS * width
+    shared = sum(1 for s in range(strips) if _shared_index(s, split) is not None)
+    return ((shared + world - 1) // world) * STRIP_ROWS * width
 
 
-def strip_rows_of_rank(height, rank, world):
-    """Global rows owned by `rank`, in the order they appear in its compact buffer."""
+def private_rows_host(height, split):
+    """Global rows of the private strips (rendered by the root straight into the image)."""
+    return [r for r in range(height) if _shared_index(r // STRIP_ROWS, split) is None]
+
+
+def strip_rows_of_rank(height, rank, world, split=(0, 1)):
+    """Global rows of the shared strips owned by `rank`, in the order they appear in its compact buffer."""
     rows = []
     strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
-    for s in range(rank, strips, world):
+    for s in range(strips):
+        t = _shared_index(s, split)
+        if t is None or t % world != rank:
+            continue
         for k in range(STRIP_ROWS):
             if s * STRIP_ROWS + k < height:
                 rows.append(s * STRIP_ROWS + k)

@@ -36,6 +36,7 @@ struct sdfr_renderer
 	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
 	bool profiling = false;
 	int tile_w_log2 = 3;
+	int priv_count = 0, priv_period = 1; // sdfr_set_strip_split
 	FrameU U;
 	host::ShaderVariableManager vars;
 	std::vector<std::string> scene_var_slots; // slot k of FrameU::scene_var <- this variable
@@ -458,18 +459,34 @@ int sdfr_set_schedule(sdfr_renderer *r, int schedule)
 	return SDFR_OK;
 }
 
-int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format)
+int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format) { return sdfr_strip_buffer_bytes_split(width, height, world, format, 0, 1); }
+
+int64_t sdfr_strip_buffer_bytes_split(int width, int height, int world, int format, int priv_count, int priv_period)
 {
-	const int64_t n = sdfr_strip_buffer_pixels(width, height, world);
+	const int64_t n = sdfr_strip_buffer_pixels_split(width, height, world, priv_count, priv_period);
 	if (n < 0 || (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8)) return -1;
 	return (int64_t)image_bytes((size_t)n, format);
 }
 
 int64_t sdfr_strip_buffer_pixels(int width, int height, int world)
 {
-	if (width < 1 || height < 1 || world < 1) return 0;
+	return sdfr_strip_buffer_pixels_split(width, height, world, 0, 1);
+}
+
+int64_t sdfr_strip_buffer_pixels_split(int width, int height, int world, int priv_count, int priv_period)
+{
+	if (width < 1 || height < 1 || world < 1 || priv_count < 0 || priv_period < 1 || priv_count >= priv_period) return 0;
 	const int64_t strips = ((int64_t)height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS;
-	return ((strips + world - 1) / world) * SDFR_STRIP_ROWS * (int64_t)width;
+	const int64_t shared = strips - (int64_t)private_strip_count((uint32_t)strips, priv_count, priv_period);
+	return ((shared + world - 1) / world) * SDFR_STRIP_ROWS * (int64_t)width;
+}
+
+int sdfr_set_strip_split(sdfr_renderer *r, int priv_count, int priv_period)
+{
+	if (!r || priv_count < 0 || priv_period < 1 || priv_count >= priv_period || priv_period > 4096) return SDFR_ERR_INVALID_ARGUMENT;
+	r->priv_count = priv_count;
+	r->priv_period = priv_period;
+	return SDFR_OK;
 }
 
 // latch the variable values into the frame uniforms (the reference uploads them every frame,
@@ -498,12 +515,16 @@ static int latch_frame(sdfr_renderer *r, int width, int height)
 	return SDFR_OK;
 }
 
+enum RenderMode { RENDER_FULL, RENDER_STRIPS, RENDER_PRIVATE };
+
 static int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
-	bool strips)
+	RenderMode mode)
 {
 	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+	const bool strips = mode == RENDER_STRIPS;
 	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && !(strips && format == SDFR_STRIP_RGB32F_A8))
 		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	if (mode == RENDER_PRIVATE && r->priv_count == 0) return SDFR_OK; // no private strips: nothing to render
 	if (world < 1 || rank < 0 || rank >= world) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad rank/world");
 	SDFR_HIP(hipSetDevice(r->device));
 	const auto t_setup = std::chrono::steady_clock::now();
@@ -515,9 +536,18 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	rm.rank = rank;
 	rm.world = world;
 	rm.tile_w_log2 = r->tile_w_log2;
-	rm.local_rows = (int)(sdfr_strip_buffer_pixels(width, height, world) / width);
-	if (world == 1 && !strips) rm.local_rows = height; // a strip buffer keeps whole strips (rows past the frame stay zero)
-	const size_t local_pixels = (size_t)rm.local_rows * width;
+	rm.priv_count = mode == RENDER_FULL ? 0 : r->priv_count;
+	rm.priv_period = mode == RENDER_FULL ? 1 : r->priv_period;
+	rm.direct = mode == RENDER_PRIVATE ? 1 : 0;
+	const uint32_t frame_strips = (uint32_t)((height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS);
+	if (mode == RENDER_FULL)
+		rm.local_rows = height;
+	else if (mode == RENDER_STRIPS) // a strip buffer keeps whole strips (rows past the frame stay zero)
+		rm.local_rows = (int)(sdfr_strip_buffer_pixels_split(width, height, world, rm.priv_count, rm.priv_period) / width);
+	else
+		rm.local_rows = (int)(private_strip_count(frame_strips, rm.priv_count, rm.priv_period) * SDFR_STRIP_ROWS);
+	// pixels the output (and the per-pixel workspace, which is indexed like the output) spans
+	const size_t local_pixels = mode == RENDER_PRIVATE ? (size_t)width * height : (size_t)rm.local_rows * width;
 	const size_t out_bytes = image_bytes(local_pixels, format);
 
 	void *d_out = out;
@@ -551,14 +581,19 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 		// rows of the buffer past the end of the frame are never written: define them (only the ranks
 		// whose last strip is missing or cut short have any)
 		const int last_local_strip = rm.local_rows / SDFR_STRIP_ROWS - 1;
-		const long long last_row_end = ((long long)last_local_strip * world + rank) * SDFR_STRIP_ROWS + SDFR_STRIP_ROWS;
-		if (last_row_end > height) SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
+		const long long last_row_end = last_local_strip < 0 ? 0 : ((long long)strip_local_to_global(rm, (uint32_t)last_local_strip) + 1) * SDFR_STRIP_ROWS;
+		if (last_row_end > height && out_bytes) SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
 	}
 
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;
-	rc = ensure_workspace(r, (size_t)launch_work_items(width, rm), !pixel_schedule);
+	if (rm.local_rows == 0) return SDFR_OK; // e.g. every strip of a small frame is private
+	{
+		size_t need = (size_t)launch_work_items(width, rm);
+		if (need < local_pixels) need = local_pixels; // private strips index the workspace by image position
+		rc = ensure_workspace(r, need, !pixel_schedule);
+	}
 	if (rc != SDFR_OK) return rc;
 	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->scene == SDFR_SCENE_COUNT) // scenes compiled at run time exist for the PIXEL schedule only
@@ -593,12 +628,17 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 
 int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
 {
-	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, false);
+	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, RENDER_FULL);
 }
 
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format)
 {
-	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr, true);
+	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr, RENDER_STRIPS);
+}
+
+int sdfr_render_private_strips(sdfr_renderer *r, int width, int height, void *out_image, int format)
+{
+	return render_impl(r, width, height, 0, 1, out_image, format, 0, nullptr, RENDER_PRIVATE);
 }
 
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format)
@@ -606,7 +646,7 @@ int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, con
 	if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
 	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	SDFR_HIP(hipSetDevice(r->device));
-	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->stream);
+	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->priv_count, r->priv_period, r->stream);
 	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
 	return SDFR_OK;
 }

@@ -95,15 +95,37 @@ struct RenderTotals
 	unsigned long long pixels, rays, march_evals, hits;
 };
 
-// Which rows of the full frame this launch renders: local row l is global row
-// ((l / 8) * world + rank) * 8 + l % 8 (8-row strips dealt round-robin over ranks).
-// world = 1, rank = 0 is the whole frame.
+// Which rows of the full frame this launch renders.  The frame is cut into 8-row strips.  Of
+// every `priv_period` consecutive strips the first `priv_count` are PRIVATE to rank 0 -- it renders
+// them straight into the final image (they never travel) -- and the others are SHARED: dealt
+// round-robin over all ranks into compact buffers that are gathered.  priv_count = 0 (the default)
+// is plain round-robin: local row l is global row ((l / 8) * world + rank) * 8 + l % 8; world = 1,
+// rank = 0 is then the whole frame.
 struct RowMap
 {
 	int local_rows;
 	int rank, world;
 	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
+	int priv_count, priv_period; // 0 <= priv_count < priv_period
+	int direct;                  // 1: this launch renders the private strips, pixel index = position in the full image
 };
+
+// local strip index of this launch -> strip index in the frame
+SDF_HD uint32_t strip_local_to_global(const RowMap &rm, uint32_t ls)
+{
+	if (rm.direct) return (ls / (uint32_t)rm.priv_count) * (uint32_t)rm.priv_period + ls % (uint32_t)rm.priv_count;
+	const uint32_t t = ls * (uint32_t)rm.world + (uint32_t)rm.rank; // index among the shared strips
+	if (rm.priv_count == 0) return t;
+	const uint32_t shared = (uint32_t)(rm.priv_period - rm.priv_count);
+	return (t / shared) * (uint32_t)rm.priv_period + (uint32_t)rm.priv_count + t % shared;
+}
+// how many strips of a frame of `strips` strips are private
+SDF_HD uint32_t private_strip_count(uint32_t strips, int priv_count, int priv_period)
+{
+	if (priv_count <= 0) return 0;
+	const uint32_t rem = strips % (uint32_t)priv_period;
+	return (strips / (uint32_t)priv_period) * (uint32_t)priv_count + (rem < (uint32_t)priv_count ? rem : (uint32_t)priv_count);
+}
 
 enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1, FORMAT_STRIP_RGB32F_A8 = 2 };
 

@@ -31,7 +31,8 @@ hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &r
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
 	int *n_rounds_out);
 
-hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream);
+hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, int priv_count,
+	int priv_period, hipStream_t stream);
 
 // HDR::process: scene16/bloom1 RGBA16F, ldr8 RGBA8, all device pointers of width*height pixels
 // mid_event (optional) is recorded between the two kernels

@@ -377,11 +377,17 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 // pixel.  RGBA32F / RGBA16F strips are copied; packed strips (12-byte rgb triples, then one flag
 // byte per pixel, per rank) expand to RGBA32F.
 __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, int world, size_t strip_pixels, const uint32_t *gathered,
-	uint32_t *image, int format)
+	uint32_t *image, int format, int priv_count, int priv_period)
 {
 	const uint32_t px = blockIdx.x * SDFR_BLOCK + threadIdx.x, py = blockIdx.y;
 	if (px >= (uint32_t)width) return;
-	const uint32_t strip = py >> 3;
+	uint32_t strip = py >> 3; // becomes the index among the shared strips
+	if (priv_count > 0)
+	{
+		const uint32_t j = strip % (uint32_t)priv_period;
+		if (j < (uint32_t)priv_count) return; // a private strip: rank 0 rendered it straight into the image
+		strip = (strip / (uint32_t)priv_period) * (uint32_t)(priv_period - priv_count) + (j - (uint32_t)priv_count);
+	}
 	const uint32_t rank = strip % (uint32_t)world, local_strip = strip / (uint32_t)world;
 	const size_t lpix = ((size_t)local_strip * 8u + (py & 7u)) * (size_t)width + px;
 	const size_t g = (size_t)py * (size_t)width + px;
@@ -552,12 +558,13 @@ hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &r
 	}
 }
 
-hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, hipStream_t stream)
+hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, int priv_count,
+	int priv_period, hipStream_t stream)
 {
-	const size_t strips = ((size_t)height + 7) / 8;
+	const size_t strips = ((size_t)height + 7) / 8 - private_strip_count((uint32_t)(((size_t)height + 7) / 8), priv_count, priv_period);
 	const size_t strip_pixels = ((strips + world - 1) / world) * 8 * (size_t)width;
 	hipLaunchKernelGGL(k_assemble, dim3((width + SDFR_BLOCK - 1) / SDFR_BLOCK, height), dim3(SDFR_BLOCK), 0, stream, width, height, world, strip_pixels,
-		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), format);
+		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), format, priv_count, priv_period);
 	return hipGetLastError();
 }
 

@@ -51,18 +51,18 @@ __device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm,
 	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
 	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
-	const int py = ((lrow >> 3) * rm.world + rm.rank) * 8 + (lrow & 7);
+	const int py = (int)(strip_local_to_global(rm, (uint32_t)lrow >> 3) * 8u) + (lrow & 7);
 	if (py >= U.height) return false;
 	pc.px = px;
 	pc.py = py;
-	pc.pid = (uint32_t)lrow * (uint32_t)U.width + (uint32_t)px;
+	pc.pid = (uint32_t)(rm.direct ? py : lrow) * (uint32_t)U.width + (uint32_t)px;
 	return true;
 }
 __device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, uint32_t pid, int &px, int &py)
 {
 	const uint32_t lrow = pid / (uint32_t)U.width;
 	px = (int)(pid - lrow * (uint32_t)U.width);
-	py = (int)(((lrow >> 3) * (uint32_t)rm.world + (uint32_t)rm.rank) * 8u + (lrow & 7u));
+	py = rm.direct ? (int)lrow : (int)(strip_local_to_global(rm, lrow >> 3) * 8u + (lrow & 7u));
 }
 // n_pixels = pixels of this launch's (compact) image: the packed strip format keeps its flag
 // bytes behind the n_pixels rgb triples

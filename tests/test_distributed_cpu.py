@@ -72,6 +72,11 @@ def test_strip_partition_covers_every_row_once():
 
     for h in (1, 7, 8, 9, 27, 64, 2160):
         for world in (1, 2, 3, 4, 8):
-            rows = sorted(r for k in range(world) for r in sp.strip_rows_of_rank(h, k, world))
-            assert rows == list(range(h))
-            assert all(len(sp.strip_rows_of_rank(h, k, world)) * 1 <= sp.strip_buffer_pixels_host(1, h, world) for k in range(world))
+            for split in ((0, 1), (1, 4), (5, 16), (3, 4)):
+                rows = sorted([r for k in range(world) for r in sp.strip_rows_of_rank(h, k, world, split)] + sp.private_rows_host(h, split))
+                assert rows == list(range(h)), (h, world, split)
+                assert all(len(sp.strip_rows_of_rank(h, k, world, split)) <= sp.strip_buffer_pixels_host(1, h, world, split) for k in range(world))
+                # rows sit in a rank's buffer in increasing order, whole strips at 8-row boundaries
+                for k in range(world):
+                    rk = sp.strip_rows_of_rank(h, k, world, split)
+                    assert rk == sorted(rk)

@@ -333,3 +333,47 @@ def test_kernels_reproduce_256x256_digests(renderer, case):
         assert hashlib.sha256(st.tobytes()).hexdigest() == case["stats_sha256"]
         s = renderer.getStats()
         assert [s.pixels, s.rays, s.march_evals, s.hits] == case["totals"]
+
+
+@pytest.mark.parametrize("world,split", [(2, (5, 16)), (4, (1, 4)), (8, (3, 16)), (1, (3, 4)), (3, (15, 16))])
+def test_private_strips_plus_shared_strips_make_the_full_frame(renderer, oracle, world, split):
+    """Unequal shares: the root renders the private strips straight into the image, all ranks share
+    the rest (sdfr_set_strip_split); emulated on one GPU, both schedules, packed transport."""
+    import torch
+    import sdf_playground_amd as sp
+
+    w, h = 200, 139
+    _setup(renderer, oracle, "labyrinth", 0.75)
+    renderer.setStripSplit(0, 1)
+    renderer.setSchedule(1)
+    full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    renderer.render(None, w, h, out=full)
+    try:
+        for schedule in (1, 0):
+            renderer.setSchedule(schedule)
+            renderer.setStripSplit(*split)
+            n = sp.strip_buffer_pixels(w, h, world, split)
+            assert n == sp.strip_buffer_pixels_host(w, h, world, split)
+            nbytes = sp.strip_buffer_bytes(w, h, world, sp.STRIP_RGB32F_A8, split)
+            packed = torch.full((world, nbytes), 0xCD, dtype=torch.uint8, device="cuda")
+            for rank in range(world):
+                renderer.renderStrips(w, h, rank, world, packed[rank], fmt=sp.STRIP_RGB32F_A8)
+            out = torch.full((h, w, 4), -7.0, dtype=torch.float32, device="cuda")
+            renderer.renderPrivateStrips(w, h, out)
+            renderer.sync()
+            # exactly the private rows are written by the private render
+            priv = sp.private_rows_host(h, split)
+            mask = torch.zeros(h, dtype=torch.bool, device="cuda")
+            mask[priv] = True
+            assert torch.equal(out[mask].view(torch.int32), full[mask].view(torch.int32))
+            assert bool((out[~mask] == -7.0).all())
+            renderer.assembleStrips(w, h, world, packed, out, fmt=sp.STRIP_RGB32F_A8)
+            renderer.sync()
+            assert torch.equal(out.view(torch.int32), full.view(torch.int32)), (schedule, world, split)
+            # the host statement of the layout agrees
+            unpacked = np.stack([sp.unpack_strip_host(packed[r].cpu().numpy(), n) for r in range(world)])
+            img = sp.assemble_strips_host(w, h, world, unpacked, split, image=np.where(mask.cpu().numpy()[:, None, None], full.cpu().numpy(), 0).astype(np.float32))
+            assert np.array_equal(img, full.cpu().numpy())
+    finally:
+        renderer.setStripSplit(0, 1)
+        renderer.setSchedule(1)
