@@ -40,6 +40,7 @@ import sdf_playground_amd as sp
 SCENE = "labyrinth"
 WIDTH, HEIGHT = 3840, 2160
 ITER_COUNT = 256
+SPLIT_PERIOD = 16     # strips per period of the private/shared split (N > 1)
 SEED = 0x5DF00003
 SWEEP = 16
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec)
@@ -150,6 +151,9 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--force-distributed", action="store_true", help="take the strips + gather path even with one rank (testing)")
     ap.add_argument("--verify", action="store_true", help="after timing, check rank 0's assembled image of the last frame against a direct render")
+    ap.add_argument("--private-strips", default="auto",
+                    help="N > 1: of every 16 strips, how many rank 0 renders privately (its pixels do not travel); 'auto' = chosen from the "
+                         "render and gather times measured during start-up")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,34 +198,103 @@ def main():
         rr[1].setLimits(iter_count=ITER_COUNT)
         rr[1].setSchedule(schedule)
         rr[1].setStream(rs[1].cuda_stream)
-        # strips travel in the packed lossless format: 13 bytes per pixel instead of 16 (alpha is a flag)
-        n_bytes = sp.strip_buffer_bytes(W, H, world, sp.STRIP_RGB32F_A8)
-        local = [torch.empty((n_bytes,), dtype=torch.uint8, device="cuda") for _ in range(2)]
-        gathered_flat = [torch.empty((world, n_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
-        gather_lists = [list(g.unbind(0)) for g in gathered_flat] if rank == 0 else None
-        works = [None, None]
         side = torch.cuda.Stream()
-        asm_done = [torch.cuda.Event(), torch.cuda.Event()]
-        asm_used = [False, False]
         if rank == 0:
-            r_asm = sp.SDFRenderer(local_rank)  # a second handle bound to the side stream, for the assembly kernel
+            r_asm = sp.SDFRenderer(local_rank)  # a handle bound to the side stream, for the assembly kernel
             r_asm.setStream(side.cuda_stream)
-    image = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+            # private strips (see below) are rendered by handles of their own, so that counters do not mix
+            r_priv = [sp.SDFRenderer(local_rank), sp.SDFRenderer(local_rank)]
+            for b in range(2):
+                r_priv[b].initShader(SCENE)
+                r_priv[b].setLimits(iter_count=ITER_COUNT)
+                r_priv[b].setSchedule(schedule)
+                r_priv[b].setStream(rs[b].cuda_stream)
+    # the assembled frames, double-buffered like everything else that two frames in flight share
+    images = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if distributed else 1)]
+    image = images[0]
 
     cameras = [make_camera(k, W, H) for k in range(SWEEP)]
 
+    split = (0, SPLIT_PERIOD)
+    calibration = None
+    if distributed:
+        # ---- how much of the frame should rank 0 keep for itself? ---------------------------------------
+        # Its own pixels never cross a link, and for N > 1 the frame rate is bounded by what the peers
+        # push through their single link each.  Measured here, once: a full-frame render (t_full), and a
+        # gather + assembly of equal shares with nothing to render (t_gather).  With p = m / 16 of the
+        # strips private: rank 0 renders t_full * (p + (1 - p) / N) and assembles, the links carry
+        # t_gather * (1 - p); the frame time is the larger one (they overlap: two frames in flight).
+        def make_buffers(sp_split):
+            nb = sp.strip_buffer_bytes(W, H, world, sp.STRIP_RGB32F_A8, sp_split)
+            loc = [torch.empty((nb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            gat = [torch.empty((world, nb), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
+            return loc, gat, ([list(g.unbind(0)) for g in gat] if rank == 0 else None)
+
+        local, gathered_flat, gather_lists = make_buffers(split)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(2):
+            r.setParameters(cameras[k][1]); r.setCamera(cameras[k][0]); r.render(None, W, H, out=image)
+        e0.record(stream)
+        for k in range(4):
+            r.setParameters(cameras[k][1]); r.setCamera(cameras[k][0]); r.render(None, W, H, out=image)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t_full = e0.elapsed_time(e1) / 4
+
+        def gather_once(b):
+            with torch.cuda.stream(side):  # the collective orders itself after, and the assembly behind, this stream
+                if rank == 0:
+                    dist.gather(local[b], gather_list=gather_lists[b], dst=0)
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=sp.STRIP_RGB32F_A8)
+                else:
+                    dist.gather(local[b], dst=0)
+
+        for b in range(2):
+            local[b].zero_()
+        torch.cuda.synchronize()
+        for b in range(2):
+            gather_once(b)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0g = time.perf_counter()
+        for i in range(6):
+            gather_once(i & 1)
+        torch.cuda.synchronize()
+        t_gather = (time.perf_counter() - t0g) / 6 * 1e3
+        choice = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if rank == 0:
+            if a.private_strips != "auto":
+                m_best = max(0, min(SPLIT_PERIOD - 1, int(a.private_strips)))
+            else:
+                m_best, t_best = 0, None
+                for m in range(0, SPLIT_PERIOD - 1):
+                    p_ = m / SPLIT_PERIOD
+                    t_m = max(t_full * (p_ + (1 - p_) / world), t_gather * (1 - p_))
+                    if t_best is None or t_m < t_best * 0.97:   # prefer the smaller split unless it clearly pays
+                        m_best, t_best = m, t_m
+            choice[0] = m_best
+        dist.broadcast(choice, src=0)
+        split = (int(choice.item()), SPLIT_PERIOD)
+        calibration = {"t_full_ms": t_full, "t_gather_ms": t_gather, "private_strips_of_16": split[0]}
+        for h_ in rr + ([r_asm] + r_priv if rank == 0 else []):
+            h_.setStripSplit(*split)
+        local, gathered_flat, gather_lists = make_buffers(split)
+        works = [None, None]
+        asm_done = [torch.cuda.Event(), torch.cuda.Event()]
+        asm_used = [False, False]
+
     def step(s):
-        """Enqueue frame s; returns the handle that renders it."""
+        """Enqueue frame s; returns the handles that render it (their counters add up to this rank's share)."""
         cam, stime = cameras[s % SWEEP]
         if not distributed:
             r.setParameters(stime)
             r.setCamera(cam)
             r.render(None, W, H, out=image)
-            return r
+            return [r]
         b = s & 1
         h = rr[b]
         h.setParameters(stime)
         h.setCamera(cam)
+        used = [h]
         with torch.cuda.stream(rs[b]):
             if works[b] is not None:
                 works[b].wait()                    # this frame's stream: local[b] is free once gather s-2 is done
@@ -230,14 +303,20 @@ def main():
             h.renderStrips(W, H, rank, world, local[b], fmt=sp.STRIP_RGB32F_A8)
             if rank == 0:
                 works[b] = dist.gather(local[b], gather_list=gather_lists[b], dst=0, async_op=True)
+                if split[0] > 0:  # after the gather was issued: the private strips render while the peers' strips travel
+                    hp = r_priv[b]
+                    hp.setParameters(stime)
+                    hp.setCamera(cam)
+                    hp.renderPrivateStrips(W, H, images[b])
+                    used.append(hp)
                 with torch.cuda.stream(side):
                     works[b].wait()
-                    r_asm.assembleStrips(W, H, world, gathered_flat[b], image, fmt=sp.STRIP_RGB32F_A8)
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=sp.STRIP_RGB32F_A8)
                     asm_done[b].record(side)
                     asm_used[b] = True
             else:
                 works[b] = dist.gather(local[b], dst=0, async_op=True)
-        return h
+        return used
 
     def fence():
         torch.cuda.synchronize()
@@ -264,9 +343,9 @@ def main():
     rays_per_frame = []
     kernel_ms = []
     for k in range(min(SWEEP, a.steps)):
-        st = step(k).getStats()
-        rays_per_frame.append(int(st.rays))
-        kernel_ms.append(st.ms_gpu)
+        sts = [h_.getStats() for h_ in step(k)]
+        rays_per_frame.append(sum(int(st.rays) for st in sts))
+        kernel_ms.append(sum(st.ms_gpu for st in sts))
     my_rays = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(a.steps))
     step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
 
@@ -282,9 +361,8 @@ def main():
     if a.verify and rank == 0:
         last = a.steps - 1
         step(last)
-        fence_local = torch.cuda.synchronize
-        fence_local()
-        got = image.clone()
+        torch.cuda.synchronize()
+        got = images[last & 1 if distributed else 0].clone()
         cam, stime = make_camera(last % SWEEP, W, H)
         r.setParameters(stime)
         r.setCamera(cam)
@@ -315,6 +393,7 @@ def main():
                 "workload": "labyrinth %dx%d, iter_count %d, reference cost rules (max_cost 7, hard shadows), 16-frame fixed-seed camera sweep (seed 0x5DF00003), default variables" % (W, H, ITER_COUNT),
                 "schedule": "pixel" if schedule == sp.SCHEDULE_PIXEL else "wavefront",
                 "parallelism": "strips%d" % world if distributed else "single",
+                "strip_calibration": calibration,
                 "rays_per_pixel": total_rays / a.steps / (W * H),
             },
         }

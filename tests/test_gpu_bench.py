@@ -33,3 +33,13 @@ def test_bench_strip_pipeline_assembles_the_same_image():
     d = _run(["--force-distributed"])
     assert d["verified"] is True
     assert d["config"]["parallelism"] == "strips1" and d["scaling"] == "strong"
+    cal = d["config"]["strip_calibration"]
+    assert cal["t_full_ms"] > 0 and cal["t_gather_ms"] > 0 and 0 <= cal["private_strips_of_16"] < 16
+
+
+def test_bench_strip_pipeline_with_private_strips():
+    """rank 0 keeps 5 of every 16 strips for itself (rendered straight into the image, never gathered)"""
+    d = _run(["--force-distributed", "--private-strips", "5"])
+    assert d["verified"] is True and d["config"]["strip_calibration"]["private_strips_of_16"] == 5
+    # same frames, same rays as the plain pipeline
+    assert abs(d["config"]["rays_per_pixel"] - _run(["--force-distributed", "--private-strips", "0"])["config"]["rays_per_pixel"]) < 1e-12
