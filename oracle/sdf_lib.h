@@ -305,7 +305,7 @@ inline real opRepInf(real pos, real size)
 inline real opRepAngle(float2 &pos, real count)
 {
 	real angle = r_atan2(pos.y, pos.x);
-	real reduced_angle = angle * count / real(tau) + real(0.5f);
+	real reduced_angle = r_div_const(angle * count, real(tau)) + real(0.5f);
 	real index = r_floor(reduced_angle);
 	reduced_angle -= index;
 	angle = (reduced_angle - real(0.5f)) * real(tau) / count;

@@ -148,7 +148,7 @@ SDF_HD vec3 op_rep_inf(vec3 p, vec3 size) { return V3(op_rep_inf(p.x, size.x), o
 SDF_HD float op_rep_angle(vec2 *p, float count)
 {
 	float angle = atan21(p->y, p->x);
-	float reduced = angle * count / SDFR_TAU + 0.5f;
+	float reduced = div_c(angle * count, SDFR_TAU, 1.0f / SDFR_TAU) + 0.5f; // tau is on the verified-divisor list
 	float index = floor1(reduced);
 	reduced = reduced - index;
 	angle = (reduced - 0.5f) * SDFR_TAU / count;

@@ -14,6 +14,7 @@ SCENE_DIVISORS = [
     20.0,                                              # labyrinth cell size
     3.0, 10.0,                                         # lense background cells
     15.0,                                              # turbulence3 normalisation
+    float(np.float32(6.28318530717958647)),            # op_rep_angle: angle * count / tau
     float(np.float32(np.float32(np.float32(1.41421356237309504) * np.float32(0.1)) / np.float32(4.0))),  # op_pipe period (labyrinth vase)
 ]
 # tree: the branch generations' scales 1.4^-i, formed like the scene does (repeated fp32 division)
