@@ -202,7 +202,7 @@ int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity);
  * domain (sdf_playground_amd/csrc/sdfr_math.h: sqrt1, div_c).  This runs the exhaustive
  * comparison on the GPU and returns the number of differing inputs (expected: 0).
  *   what = 0             sqrt1(a)   vs IEEE sqrt   for a = +0 and all a in [2^-96, FLT_MAX]
- *   what = 1, constant c a / c      vs IEEE divide for a = +-0 and all 2^-100 <= |a| <= 2^100
+ *   what = 1, constant c a / c      vs IEEE divide for a = +-0 and all 2^-100 <= |a| <= 2^110
  *   what = 2, constant c negative control: a * (1/c) vs IEEE divide on the same inputs (> 0)
  *   what = 3, constant c as 1 but for a = +-0 and all 2^-60 <= |a| <= 2^40 (fast ground plane) */
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches);

@@ -44,7 +44,7 @@ inline void census_check_sqrt(float a)
 inline void census_check_divc(float a)
 {
 	float m = fabsf(a);
-	if (a != a || m > 0x1p100f) census().far_field++;
+	if (a != a || m > 0x1p110f) census().far_field++;
 	else if (!(m == 0.f || m >= 0x1p-100f)) census().divc_out_of_domain++;
 }
 inline void census_check_plane(float a, float c)

@@ -360,7 +360,7 @@ inline real staircase(real x, real stepval, real spread)
 // :118-122
 inline real smin(real a, real b, real k)
 {
-	real h = r_saturate(real(0.5f) + real(0.5f) * (b - a) / k);
+	real h = r_saturate(real(0.5f) + r_div_const(real(0.5f) * (b - a), k)); // census: numerator domain of the kernels' div_c
 	return r_lerp(b, a, h) - k * h * (real(1.f) - h);
 }
 // :125-129
@@ -372,7 +372,7 @@ inline real smax1(real a, real b, real k)
 // :131-135
 inline real smax2(real a, real b, real k)
 {
-	real h = r_saturate(real(0.5f) - real(0.5f) * (b - a) / k);
+	real h = r_saturate(real(0.5f) - r_div_const(real(0.5f) * (b - a), k));
 	return r_lerp(b, a, h) + k * h * (real(1.f) - h);
 }
 

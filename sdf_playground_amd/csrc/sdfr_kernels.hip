@@ -410,7 +410,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, 
 
 // ---- self-test of the fast exact arithmetic (sdfr_math.h: sqrt1, div_c) ------------------------------
 // what = 0: sqrt1(a) against the generic IEEE lowering for a = +0 and every a in [2^-96, FLT_MAX]
-// what = 1: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-100 <= |a| <= 2^100
+// what = 1: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-100 <= |a| <= 2^110
 // what = 2: negative control -- the plain reciprocal multiply a * (1/c) on the same inputs (must differ)
 // what = 3: div_c(a, c, 1/c) against a / c for a = +0 and every 2^-60 <= |a| <= 2^40 (the fast
 //           ground plane: numerator = height above the floor, c = per-ray denominator in [1e-20, 2])
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_selftest_math(int what, float c,
 			{
 				if (!(m == 0.f) && !(m >= 0x1p-60f && m <= 0x1p40f)) continue;
 			}
-			else if (!(m == 0.f) && !(m >= 0x1p-100f && m <= 0x1p100f))
+			else if (!(m == 0.f) && !(m >= 0x1p-100f && m <= 0x1p110f)) // up to 2^110: the smooth minima start from a 3e30 sentinel
 				continue;
 			ref = a / c;
 			got = what == 2 ? a * rc : div_c(a, c, rc);

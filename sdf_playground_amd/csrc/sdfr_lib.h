@@ -210,6 +210,17 @@ SDF_HD float op_smin(float a, float b, float k)
 	float h = sat1(0.5f + 0.5f * (b - a) / k);
 	return lerp1(b, a, h) - k * h * (1.f - h);
 }
+// the same with a literal k from the verified-divisor list (div_c): pass rk = 1.0f / k
+SDF_HD float op_smin_c(float a, float b, float k, float rk)
+{
+	float h = sat1(0.5f + div_c(0.5f * (b - a), k, rk));
+	return lerp1(b, a, h) - k * h * (1.f - h);
+}
+SDF_HD float op_smax2_c(float a, float b, float k, float rk)
+{
+	float h = sat1(0.5f - div_c(0.5f * (b - a), k, rk));
+	return lerp1(b, a, h) + k * h * (1.f - h);
+}
 SDF_HD float op_smax1(float a, float b, float k)
 {
 	float h = sat1(0.5f - 0.5f * (b + a) / k);

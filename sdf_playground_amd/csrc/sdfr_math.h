@@ -138,7 +138,7 @@ SDF_HD float rsqrt1(float a) { return rcp1(sqrt1(a)); }
 //     that a = -0 gives -0: the residual of a zero numerator must be -0, not +0)
 // instead of the ~11-instruction IEEE divide.  Bit-identical to a / c whenever no
 // intermediate under- or overflows: exhaustively checked for the constants the scenes use
-// (sdfr_selftest_math) over a = +-0 and 2^-100 <= |a| <= 2^100.  Only for verified constants.
+// (sdfr_selftest_math) over a = +-0 and 2^-100 <= |a| <= 2^110.  Only for verified constants.
 SDF_HD float div_c(float a, float c, float rc)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -513,7 +513,7 @@ struct SceneGems
 		float plane1 = sd_plane(q - V3(0.1f, 0.1f, 0.f), V3(0.707f, 0.707f, 0.f));
 		float plane2 = sd_plane(q, V3(0.707f, -0.707f, 0.f));
 		float plane3 = sd_plane(q - V3(0.f, 0.13f, 0.f), V3(0.f, 1.f, 0.f));
-		return op_smax2(op_smax2(plane1, plane2, 0.001f), plane3, 0.001f);
+		return op_smax2_c(op_smax2_c(plane1, plane2, 0.001f, 1.0f / 0.001f), plane3, 0.001f, 1.0f / 0.001f);
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{

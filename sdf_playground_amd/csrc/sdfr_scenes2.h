@@ -351,7 +351,7 @@ struct SceneTable
 		const float s3 = sd_sphere(p - V3(0.f, leg_height + 0.72f, 0.f), 0.15f);
 		const float cut_top = sd_plane(p - V3(0.f, leg_height + 0.615f, 0.f), V3(0.f, 1.f, 0.f));
 		const float cut_low = sd_plane(p - V3(0.f, leg_height + 0.1f, 0.f), V3(0.f, -1.f, 0.f));
-		const float body = max1(op_smin(op_smin(s1, s2, 0.05f), s3, 0.025f), cut_low);
+		const float body = max1(op_smin_c(op_smin_c(s1, s2, 0.05f, 1.0f / 0.05f), s3, 0.025f, 1.0f / 0.025f), cut_low);
 		o.vase = max1(max1(body, cut_top), -body - 0.01f);
 		return o;
 	}

@@ -46,7 +46,7 @@ struct SceneTree
 			// (exact for all nine constants: tests/test_gpu_math.py, SCENE_DIVISORS)
 			const float inv_scale = 1.0f / tree_scale;
 			const vec3 ps = V3(div_c(p.x, tree_scale, inv_scale), div_c(p.y, tree_scale, inv_scale), div_c(p.z, tree_scale, inv_scale));
-			t = op_smin(t, branch(ps, 1.f, 0.1f, 0.05f) * tree_scale, 0.01f);
+			t = op_smin_c(t, branch(ps, 1.f, 0.1f, 0.05f) * tree_scale, 0.01f, 1.0f / 0.01f);
 			l = min1(l, sd_sphere(ps - V3(0.f, 1.f + ball * leaf_scale, 0.f), ball * leaf_scale) * tree_scale);
 
 			const float height = i == 0 ? height0 : 0.41f;

@@ -15,6 +15,7 @@ SCENE_DIVISORS = [
     3.0, 10.0,                                         # lense background cells
     15.0,                                              # turbulence3 normalisation
     float(np.float32(6.28318530717958647)),            # op_rep_angle: angle * count / tau
+    float(np.float32(0.001)), float(np.float32(0.05)), float(np.float32(0.025)), float(np.float32(0.01)),   # smooth min / max widths (gems, table, tree)
     float(np.float32(np.float32(np.float32(1.41421356237309504) * np.float32(0.1)) / np.float32(4.0))),  # op_pipe period (labyrinth vase)
 ]
 # tree: the branch generations' scales 1.4^-i, formed like the scene does (repeated fp32 division)
