@@ -1,6 +1,6 @@
 """GPU tier: a short, seeded run of the randomised parity hunt (tools/fuzz_parity.py): random
 cameras (also far away, grazing the floor), times, variable values, limits and schedules for all
-22 scenes against the oracle, bit for bit.  The long runs (160 000 cases in round 1, no mismatch) are
+22 scenes against the oracle, bit for bit.  The long runs (190 000 cases in round 1, no mismatch) are
 recorded in profiles/README.md."""
 import os
 import sys
