@@ -140,7 +140,7 @@ struct SceneFractal2
 		real scale = 1.f;
 		for (uint i = 0; i < 6; ++i)
 		{
-			real new_d = sdBox(fractal_pos, size * real(0.5f)) / scale;
+			real new_d = r_div_const(sdBox(fractal_pos, size * real(0.5f)), scale); // census: numerator domain of the kernels' div_c
 			fractal = r_min(fractal, new_d);
 
 			fractal_pos = v_abs(fractal_pos);

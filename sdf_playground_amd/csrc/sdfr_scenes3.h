@@ -28,7 +28,7 @@ struct SceneFractal2
 #pragma unroll
 		for (int i = 0; i < 6; ++i)
 		{
-			d = min1(d, sd_box(q, V3s(size * 0.5f)) / scale);
+			d = min1(d, div_c(sd_box(q, V3s(size * 0.5f)), scale, 1.0f / scale)); // scale = 3^i: verified divisors
 			q = abs(q);
 			sort3_desc(q.y, q.x, q.z);
 			q.y = q.y - size * 2.f / 3.f;
