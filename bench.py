@@ -437,6 +437,40 @@ def main():
         out["host_enqueue_ms_per_step"] = enqueue_ms
         if verified is not None:
             out["verified"] = verified
+        if not distributed:
+            # Not the headline: the same sweep with TWO frames in flight (two handles on two streams),
+            # measured after the timed region.  It shows how much of `ms_per_step` is the tail of a
+            # frame (the last few waves march their 256-step rays alone); `value` and `roofline` above
+            # stay on one frame in flight, where a kernel's duration is its own.
+            try:
+                s2 = torch.cuda.Stream()
+                r2 = sp.SDFRenderer(local_rank)
+                r2.initShader(SCENE)
+                r2.setLimits(iter_count=ITER_COUNT)
+                r2.setSchedule(schedule)
+                r2.setStream(s2.cuda_stream)
+                img2 = torch.empty_like(image)
+                pair = [(r, image), (r2, img2)]
+
+                def step2(k):
+                    h_, im_ = pair[k & 1]
+                    h_.setParameters(cameras[k % SWEEP][1])
+                    h_.setCamera(cameras[k % SWEEP][0])
+                    h_.render(None, W, H, out=im_)
+
+                for k in range(4):
+                    step2(k)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for k in range(a.steps):
+                    step2(k)
+                torch.cuda.synchronize()
+                ms2 = (time.perf_counter() - t2) / max(1, a.steps) * 1e3
+                out["two_frames_in_flight"] = {"ms_per_step": ms2, "value": total_rays / a.steps / (ms2 * 1e-3) / 1e6, "unit": "Mrays/s",
+                                               "note": "informational: same frames, two streams; not the headline"}
+                r2.close()
+            except Exception as e:
+                out["two_frames_in_flight"] = {"error": repr(e)}
         if not distributed and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
