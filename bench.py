@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5|5g]
 
-Workload (BASELINE.json configs[2], concretised in SURVEY.md 8(d) cfg 3): the `labyrinth`
-scene at 3840x2160, iter_count 256, reference cost rules, default variables, on the fixed-seed
-16-frame camera sweep  eye = (1.5 cos t, 5, 1.5 sin t), dir = (cos t, -0.35, sin t),
+Headline workload (BASELINE.json configs[2], concretised in SURVEY.md 8(d) cfg 3; --config 3, the
+default): the `labyrinth` scene at 3840x2160, iter_count 256, reference cost rules, default variables,
+on the fixed-seed 16-frame camera sweep  eye = (1.5 cos t, 5, 1.5 sin t), dir = (cos t, -0.35, sin t),
 t = 2 pi (k + u_k) / 16, u_k = pcg_hash(0x5DF00003 + k) / 4294967295, stime = k / 60.
-One "step" = one full frame through the hot path (step s renders sweep frame s % 16).
-Metric: Mrays/s, ray := one iteration of the reference's bounce loop (primary + secondary).
+The other BASELINE configurations (SURVEY.md 8(d) cfg 2, 4, 5) run with --config; they are measured
+for profiles/, they are not the headline.  One "step" = one full frame through the hot path (step s
+renders sweep frame s % 16).  Metric: Mrays/s, ray := one iteration of the reference's bounce loop
+(primary + secondary).
 
-N > 1 (launched by torch.distributed.run, one process per GPU): each frame is cut into 8-row
-strips dealt round-robin over the ranks (strong scaling: the frame is fixed), every rank
-renders its strips into a compact buffer, one RCCL gather per frame moves them to rank 0,
-which scatters them into the image (double-buffered: gather and assembly of frame k overlap
-the render of frame k+1).  value = rays of all ranks / max-over-ranks time.
+N > 1: one process per GPU.  Started by torch.distributed.run (the driver's way: RANK / LOCAL_RANK /
+WORLD_SIZE in the environment), or -- when WORLD_SIZE is not set -- by this script itself, which
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process BEFORE
+anything touches a GPU and relays rank 0's line and the exit code.  Each frame is cut into 8-row
+strips dealt round-robin over the ranks (strong scaling: the frame is fixed); the library renders
+this rank's strips and gathers them on rank 0 with RCCL (sdfr_render_gather: ncclSend / ncclRecv over
+xGMI, strips travel as SDFR_STRIP_RGB16F_A8, the reference's RGBA16F target in 7 bytes per pixel);
+two frames are in flight on two handles.  value = rays of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,6 +27,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,21 +39,13 @@ if ROOT not in sys.path:
 # sharing fails with hipIpcGetMemHandle (already exported by the image; kept for bare shells)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-
-import sdf_playground_amd as sp
-
-SCENE = "labyrinth"
-WIDTH, HEIGHT = 3840, 2160
-ITER_COUNT = 256
-SPLIT_PERIOD = 16     # strips per period of the private/shared split (N > 1)
-SEED = 0x5DF00003
 SWEEP = 16
-PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec)
+SPLIT_PERIOD = 16     # strips per period of the private/shared split (N > 1)
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec); 2 flop per lane per FMA at the packed rate
+PEAK_VALU_LANE_OPS = 78.6e12      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: what the VALU can issue, one op per lane per cycle
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md (spec)
-CENSUS_FILE = os.path.join(ROOT, "profiles", "census_r01.json")
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r01.json")
+PROFILE_ROUND = "r02"
+CENSUS_FILE = os.path.join(ROOT, "profiles", "census_%s.json" % PROFILE_ROUND)
 
 
 def pcg_hash(x):
@@ -56,30 +55,133 @@ def pcg_hash(x):
     return ((word >> 22) ^ word) & 0xFFFFFFFF
 
 
-def sweep_camera(k):
-    """(eye, direction, stime) of sweep frame k."""
-    u = pcg_hash((SEED + k) & 0xFFFFFFFF) / 4294967295.0
-    t = 2.0 * math.pi * (k + u) / SWEEP
-    return (1.5 * math.cos(t), 5.0, 1.5 * math.sin(t)), (math.cos(t), -0.35, math.sin(t)), k / 60.0
+def _theta(seed, k):
+    return 2.0 * math.pi * (k + pcg_hash((seed + k) & 0xFFFFFFFF) / 4294967295.0) / SWEEP
 
 
-def make_camera(k, width=WIDTH, height=HEIGHT):
-    eye, direction, stime = sweep_camera(k)
+# ---- the BASELINE.json configurations as concretised by SURVEY.md 8(d) --------------------------------
+# camera(k) -> (kind, eye, target, stime); kind "dir": target is the viewing direction, "lookat": a point
+def _cam2(k):
+    t = _theta(0x5DF00002, k)
+    return "dir", (3 * math.cos(t), 4.5, 3 * math.sin(t)), (math.cos(t + 0.6), -0.45, math.sin(t + 0.6)), k / 60.0
+
+
+def _cam3(k):
+    t = _theta(0x5DF00003, k)
+    return "dir", (1.5 * math.cos(t), 5.0, 1.5 * math.sin(t)), (math.cos(t), -0.35, math.sin(t)), k / 60.0
+
+
+def _cam4(k):
+    t = _theta(0x5DF00004, k)
+    return "lookat", (2.2 * math.cos(t), 1.6, 2.2 * math.sin(t)), (0.0, 1.0, 0.0), 0.0
+
+
+def _cam5_lense(k):
+    ph = -0.5 + (k + pcg_hash((0x5DF00005 + k) & 0xFFFFFFFF) / 4294967295.0) / SWEEP
+    return "lookat", (7 * math.sin(ph), 0.5, 7 * math.cos(ph)), (0.0, 0.0, 0.0), k / 60.0
+
+
+def _cam5_gems(k):
+    t = _theta(0x5DF00005, k)
+    return "lookat", (2.5 * math.cos(t), 2.0, 2.5 * math.sin(t)), (0.0, 1.0, 0.0), k / 60.0
+
+
+CONFIGS = {
+    "2": dict(key="cube_sea_1080p_iter128", scene="cube_sea", width=1920, height=1080, limits=dict(iter_count=128, max_cost_default=6),
+              camera=_cam2, metric="Mrays/s (primary+secondary), cube_sea scene, 1920x1080",
+              workload="cube_sea %dx%d, iter_count 128, max_cost_default 6 (= exactly one reflection bounce, the configuration as worded; labelled "
+                       "extension of the reference's 100 / 7), 16-frame fixed-seed camera sweep (seed 0x5DF00002), default variables"),
+    "3": dict(key="labyrinth_4k_iter256", scene="labyrinth", width=3840, height=2160, limits=dict(iter_count=256),
+              camera=_cam3, metric="Mrays/s (primary+secondary), labyrinth scene, 3840x2160",
+              workload="labyrinth %dx%d, iter_count 256, reference cost rules (max_cost 7, hard shadows), 16-frame fixed-seed camera sweep "
+                       "(seed 0x5DF00003), default variables"),
+    "4": dict(key="fractal_4k_iter512", scene="fractal", width=3840, height=2160, limits=dict(iter_count=512),
+              camera=_cam4, metric="Mrays/s (primary+secondary), fractal scene, 3840x2160",
+              workload="fractal %dx%d, iter_count 512 (labelled extension of the reference's 100), reference cost rules, 16-frame fixed-seed camera "
+                       "sweep (seed 0x5DF00004), stime 0"),
+    "5": dict(key="lense_4k_depth4_8lights", scene="lense", width=3840, height=2160, limits=dict(iter_count=100, max_cost_default=9, extension_lights=7),
+              camera=_cam5_lense, metric="Mrays/s (primary+secondary), lense scene, 3840x2160",
+              workload="lense %dx%d, iter_count 100, max_cost_default 9 (recursion depth 4) and 7 orbiting point lights besides the scene's own "
+                       "(labelled extensions), 16-frame fixed-seed camera sweep (seed 0x5DF00005), default variables"),
+    "5g": dict(key="gems_4k_depth4_8lights", scene="gems", width=3840, height=2160, limits=dict(iter_count=100, max_cost_default=9, extension_lights=7),
+               camera=_cam5_gems, metric="Mrays/s (primary+secondary), gems scene, 3840x2160",
+               workload="gems %dx%d, iter_count 100, max_cost_default 9 (recursion depth 4) and 7 orbiting point lights besides the scene's own "
+                        "(labelled extensions), 16-frame fixed-seed camera sweep (seed 0x5DF00005), default variables"),
+}
+HEADLINE = "3"
+# names the headline keeps for tests and tools written against round 1
+SCENE, WIDTH, HEIGHT, ITER_COUNT, SEED = "labyrinth", 3840, 2160, 256, 0x5DF00003
+
+
+def sweep_camera(k, config=HEADLINE):
+    """(eye, direction-or-lookat, stime) of sweep frame k."""
+    _, eye, target, stime = CONFIGS[config]["camera"](k)
+    return eye, target, stime
+
+
+def make_camera(k, width=None, height=None, config=HEADLINE):
+    import numpy as np
+    import sdf_playground_amd as sp
+
+    cfg = CONFIGS[config]
+    width, height = width or cfg["width"], height or cfg["height"]
+    kind, eye, target, stime = cfg["camera"](k)
     cam = sp.Camera()
     cam.SetEye(eye)
-    cam.SetDirection(direction)
+    (cam.SetLookat if kind == "lookat" else cam.SetDirection)(target)
     cam.SetFOVY(sp.to_radian(60.0))
     cam.SetAspect(float(np.float32(width) / np.float32(height)))
     return cam, stime
 
 
-def load_census():
-    """flops per ray of this workload, from the operation-counting oracle build (committed)."""
+def oracle_frame(po, k, width, height, config=HEADLINE):
+    """The oracle's frame description of sweep frame k (cpu_baseline, tools/make_census.py)."""
+    import numpy as np
+    import sdf_playground_amd as sp
+
+    cfg = CONFIGS[config]
+    kind, eye, target, stime = cfg["camera"](k)
+    fovy, aspect = np.float32(sp.to_radian(60.0)), np.float32(width) / np.float32(height)
+    basis = (po.camera_lookat if kind == "lookat" else po.camera_direction)(eye, target, fovy, aspect)
+    f = po.default_frame(cfg["scene"], width, height, basis=basis, stime=stime)
+    for name, v in cfg["limits"].items():
+        setattr(f, name, v)
+    return f
+
+
+def load_census(config=HEADLINE):
+    """flops per ray of a workload, from the operation-counting oracle build (committed)."""
     try:
         with open(CENSUS_FILE) as fh:
-            return json.load(fh)["labyrinth_4k_iter256"]
+            return json.load(fh)[CONFIGS[config]["key"]]
     except Exception:
         return None
+
+
+def load_pmc(config, width, height, schedule_name):
+    """The executed-work view of the dominant kernel (rocprofv3 --pmc passes over this same command,
+    tools/collect_profiles.sh).  Returned only when the profile is of THIS workload; it is a committed
+    measurement of an earlier run, and says so (source, commit)."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s_cfg%s.json" % (PROFILE_ROUND, config))
+    try:
+        with open(path) as fh:
+            pj = json.load(fh)
+    except Exception:
+        return None
+    wl = pj.get("workload", {})
+    if wl.get("config") != config or wl.get("width") != width or wl.get("height") != height or wl.get("schedule") != schedule_name:
+        return None
+    for name, k in pj.get("kernels", {}).items():
+        if "k_pixel" in name:
+            lane_ops = k["SQ_INSTS_VALU"] * 64.0 * k["valu_lane_utilization"]
+            return {
+                "source": os.path.relpath(path, ROOT), "commit": pj.get("commit"), "measured_in_this_run": False,
+                "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "valu_lane_utilization": k["valu_lane_utilization"],
+                "cycles_per_valu_instruction_per_simd": k["cycles_per_valu_inst_per_simd"], "waves_per_simd": k["avg_waves_per_simd"],
+                "executed_lane_ops_per_launch": lane_ops, "hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"),
+                "profiled_kernel_ms": k.get("avg_ms"),
+            }
+    return None
 
 
 def host_cores():
@@ -90,13 +192,12 @@ def host_cores():
         n = min(n, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),):
-        try:
-            quota, period = parse(open(path).read())
-            if quota != "max":
-                n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
-        except Exception:
-            pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
     try:
         q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
         per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
@@ -107,26 +208,22 @@ def host_cores():
     return n
 
 
-def cpu_baseline(max_seconds=20.0):
+def cpu_baseline(config=HEADLINE, width=None, height=None, max_seconds=20.0):
     """The CPU oracle (a port: the reference HLSL cannot run here) timed on the host cores on a
     bounded sample of the same workload: the 16 sweep frames (fewer on slow hosts: it stops after
     max_seconds), every 2nd pixel in x and y; threads = the CPUs the cgroup really grants."""
     from oracle import pyoracle as po
 
+    cfg = CONFIGS[config]
+    width, height = width or cfg["width"], height or cfg["height"]
     cores = host_cores()
     step = 2
-    frames = SWEEP
-    rays = 0
-    pixels = 0
+    rays = pixels = used = 0
     t_total = 0.0
-    used = 0
-    for k in range(frames):
-        eye, direction, stime = sweep_camera(k)
-        basis = po.camera_direction(eye, direction, np.float32(sp.to_radian(60.0)), np.float32(WIDTH) / np.float32(HEIGHT))
-        f = po.default_frame(SCENE, WIDTH, HEIGHT, basis=basis, stime=stime)
-        f.iter_count = ITER_COUNT
+    for k in range(SWEEP):
+        f = oracle_frame(po, k, width, height, config)
         t0 = time.perf_counter()
-        _, _, tot = po.render(SCENE, f, step=(step, step), nthreads=cores)
+        _, _, tot = po.render(cfg["scene"], f, step=(step, step), nthreads=cores)
         t_total += time.perf_counter() - t0
         pixels += int(tot[0])
         rays += int(tot[1])
@@ -135,32 +232,128 @@ def cpu_baseline(max_seconds=20.0):
             break
     return {
         "value": rays / t_total / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": "oracle (scalar C++ restatement, g++ -O2 -ffp-contract=off), sweep frames 0..%d of the same 3840x2160 workload, every %dth pixel in x and y (%d pixels, %d rays, %.1f s)" % (used - 1, step, pixels, rays, t_total),
+        "sample": "oracle (scalar C++ restatement, g++ -O2 -ffp-contract=off), sweep frames 0..%d of the same %dx%d workload, every %dth pixel in x and y (%d pixels, %d rays, %.1f s)" % (used - 1, width, height, step, pixels, rays, t_total),
         "ms_per_frame_equiv": t_total / used * step * step * 1e3,
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="BASELINE.json configuration (SURVEY.md 8d); 3 = the headline")
     ap.add_argument("--schedule", default=os.environ.get("SDFR_SCHEDULE", "auto"), choices=["auto", "wavefront", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--no-second-pass", action="store_true",
+                    help="skip the informational two-frames-in-flight pass (N = 1): under a profiler its overlapping kernels would pollute the per-kernel statistics")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--force-distributed", action="store_true", help="take the strips + gather path even with one rank (testing)")
     ap.add_argument("--verify", action="store_true", help="after timing, check rank 0's assembled image of the last frame against a direct render")
     ap.add_argument("--private-strips", default="auto",
-                    help="N > 1: of every 16 strips, how many rank 0 renders privately (its pixels do not travel); 'auto' = chosen from the "
-                         "render and gather times measured during start-up")
-    a = ap.parse_args()
+                    help="N > 1: of every 16 strips, how many rank 0 renders privately (its pixels do not travel); 'auto' = the fastest of a few "
+                         "candidates timed during start-up")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: rccl = the library's own gather (sdfr_render_gather); torch = torch.distributed.gather of the same strips "
+                         "(also taken, on every rank, when the library's communicator cannot be made)")
+    ap.add_argument("--wire", default="f16", choices=["f16", "f32"],
+                    help="N > 1: f16 = strips and image in the reference's RGBA16F target format (7 B/pixel on the links); f32 = lossless fp32 (13 B/pixel)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="N > 1: handles / streams the frames alternate between")
+    ap.add_argument("--dry-launch", action="store_true", help="start the ranks, let each report its environment over gloo, touch no GPU (CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes with
+    torch.distributed.run and relay rank 0's JSON line and the exit code.  Runs before this process
+    has made any GPU call, and starts children -- it never replaces itself."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for l in p.stdout.splitlines():
+        try:
+            d = json.loads(l)
+            if isinstance(d, dict) and ("metric" in d or "dry_launch" in d):
+                line = l
+                continue
+        except Exception:
+            pass
+        if l.strip():
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0:
+        return p.returncode
+    return 0 if line is not None else 3
+
+
+def dry_launch(a):
+    """What a rank sees of its launch, gathered over gloo; no GPU call."""
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)   # gloo reports its connections on stdout; the contract is ONE line there
+    os.dup2(2, 1)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world_size": world, "pid": os.getpid(),
+            "master_addr": os.environ.get("MASTER_ADDR"), "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "gpus_arg": a.gpus, "ranks": every}), flush=True)
+    os.dup2(2, 1)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a, argv)      # BEFORE any GPU call (nothing below this line has run yet)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and world != a.gpus:
+        print("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, a.gpus), file=sys.stderr)
+        return 2
+    if a.dry_launch:
+        return dry_launch(a)
+    return run(a, world)
+
+
+def run(a, world):
+    import numpy as np
+    import torch
+
+    import sdf_playground_amd as sp
+
+    cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or a.force_distributed
     saved_stdout = None
+    dist = None
     if distributed:
         import torch.distributed as dist
 
@@ -177,110 +370,90 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    W, H = a.width, a.height
-
-    r = sp.SDFRenderer(local_rank)
-    r.initShader(SCENE)
-    r.setLimits(iter_count=ITER_COUNT)
+    W, H = a.width or cfg["width"], a.height or cfg["height"]
+    scene = cfg["scene"]
     schedule = {"auto": sp.SCHEDULE_PIXEL, "wavefront": sp.SCHEDULE_WAVEFRONT, "pixel": sp.SCHEDULE_PIXEL}[a.schedule]
-    r.setSchedule(schedule)
-    stream = torch.cuda.current_stream()
-    r.setStream(stream.cuda_stream)
+    schedule_name = "pixel" if schedule == sp.SCHEDULE_PIXEL else "wavefront"
 
-    if distributed:
-        # Two frames in flight.  Frames alternate between two renderer handles on two streams, so
-        # the tail of frame k (a handful of waves still marching 256-step rays: one wave alone needs
-        # ~0.2 ms, as long as a rank's whole share of the frame at 8 GPUs) overlaps the head of frame
-        # k+1; gather + assembly of frame k overlap the render of frame k+1 as well.
-        rs = [stream, torch.cuda.Stream()]
-        rr = [r, sp.SDFRenderer(local_rank)]
-        rr[1].initShader(SCENE)
-        rr[1].setLimits(iter_count=ITER_COUNT)
-        rr[1].setSchedule(schedule)
-        rr[1].setStream(rs[1].cuda_stream)
-        side = torch.cuda.Stream()
-        if rank == 0:
-            r_asm = sp.SDFRenderer(local_rank)  # a handle bound to the side stream, for the assembly kernel
-            r_asm.setStream(side.cuda_stream)
-            # private strips (see below) are rendered by handles of their own, so that counters do not mix
-            r_priv = [sp.SDFRenderer(local_rank), sp.SDFRenderer(local_rank)]
-            for b in range(2):
-                r_priv[b].initShader(SCENE)
-                r_priv[b].setLimits(iter_count=ITER_COUNT)
-                r_priv[b].setSchedule(schedule)
-                r_priv[b].setStream(rs[b].cuda_stream)
-    # the assembled frames, double-buffered like everything else that two frames in flight share
-    images = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if distributed else 1)]
+    def make_renderer(stream=None):
+        h = sp.SDFRenderer(local_rank)
+        h.initShader(scene)
+        h.setLimits(**cfg["limits"])
+        h.setSchedule(schedule)
+        if stream is not None:
+            h.setStream(stream.cuda_stream)
+        return h
+
+    stream = torch.cuda.current_stream()
+    r = make_renderer(stream)
+    cameras = [make_camera(k, W, H, a.config) for k in range(SWEEP)]
+
+    wire16 = a.wire == "f16"
+    img_fmt = sp.RGBA16F if (distributed and wire16) else sp.RGBA32F
+    img_dtype = torch.float16 if img_fmt == sp.RGBA16F else torch.float32
+    wire_fmt = sp.STRIP_RGB16F_A8 if wire16 else sp.STRIP_RGB32F_A8
+    depth = max(1, a.frames_in_flight) if distributed else 1
+    images = [torch.empty((H, W, 4), dtype=img_dtype, device="cuda") for _ in range(depth)]
     image = images[0]
 
-    cameras = [make_camera(k, W, H) for k in range(SWEEP)]
-
+    transport = None
+    comm = None
     split = (0, SPLIT_PERIOD)
     calibration = None
     if distributed:
-        # ---- how much of the frame should rank 0 keep for itself? ---------------------------------------
-        # Its own pixels never cross a link, and for N > 1 the frame rate is bounded by what the peers
-        # push through their single link each.  Measured here, once: a full-frame render (t_full), and a
-        # gather + assembly of equal shares with nothing to render (t_gather).  With p = m / 16 of the
-        # strips private: rank 0 renders t_full * (p + (1 - p) / N) and assembles, the links carry
-        # t_gather * (1 - p); the frame time is the larger one (they overlap: two frames in flight).
-        def make_buffers(sp_split):
-            nb = sp.strip_buffer_bytes(W, H, world, sp.STRIP_RGB32F_A8, sp_split)
-            loc = [torch.empty((nb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            gat = [torch.empty((world, nb), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
-            return loc, gat, ([list(g.unbind(0)) for g in gat] if rank == 0 else None)
-
-        local, gathered_flat, gather_lists = make_buffers(split)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for k in range(2):
-            r.setParameters(cameras[k][1]); r.setCamera(cameras[k][0]); r.render(None, W, H, out=image)
-        e0.record(stream)
-        for k in range(4):
-            r.setParameters(cameras[k][1]); r.setCamera(cameras[k][0]); r.render(None, W, H, out=image)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        t_full = e0.elapsed_time(e1) / 4
-
-        def gather_once(b):
-            with torch.cuda.stream(side):  # the collective orders itself after, and the assembly behind, this stream
-                if rank == 0:
-                    dist.gather(local[b], gather_list=gather_lists[b], dst=0)
-                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=sp.STRIP_RGB32F_A8)
-                else:
-                    dist.gather(local[b], dst=0)
-
-        for b in range(2):
-            local[b].zero_()
-        torch.cuda.synchronize()
-        for b in range(2):
-            gather_once(b)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        t0g = time.perf_counter()
-        for i in range(6):
-            gather_once(i & 1)
-        torch.cuda.synchronize()
-        t_gather = (time.perf_counter() - t0g) / 6 * 1e3
-        choice = torch.zeros(1, dtype=torch.int32, device="cuda")
-        if rank == 0:
-            if a.private_strips != "auto":
-                m_best = max(0, min(SPLIT_PERIOD - 1, int(a.private_strips)))
+        # frames alternate between `depth` renderer handles on as many streams, so that the tail of
+        # frame k (a handful of waves still marching long rays: one wave alone needs ~0.2 ms, as long as
+        # a rank's whole share of the frame at 8 GPUs) overlaps the head of frame k+1, and so do the
+        # transfer and the assembly of frame k
+        rs = [stream] + [torch.cuda.Stream() for _ in range(depth - 1)]
+        rr = [r] + [make_renderer(rs[b]) for b in range(1, depth)]
+        transport = a.transport
+        if transport == "rccl":
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            try:
+                ids = [sp.Comm.unique_id() if rank == 0 else None]
+            except Exception as e:
+                print("bench.py: rank %d: no communicator id (%r)" % (rank, e), file=sys.stderr)
+                ids = [None]
+                ok[0] = 0
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is None:
+                ok[0] = 0
             else:
-                m_best, t_best = 0, None
-                for m in range(0, SPLIT_PERIOD - 1):
-                    p_ = m / SPLIT_PERIOD
-                    t_m = max(t_full * (p_ + (1 - p_) / world), t_gather * (1 - p_))
-                    if t_best is None or t_m < t_best * 0.97:   # prefer the smaller split unless it clearly pays
-                        m_best, t_best = m, t_m
-            choice[0] = m_best
-        dist.broadcast(choice, src=0)
-        split = (int(choice.item()), SPLIT_PERIOD)
-        calibration = {"t_full_ms": t_full, "t_gather_ms": t_gather, "private_strips_of_16": split[0]}
-        for h_ in rr + ([r_asm] + r_priv if rank == 0 else []):
-            h_.setStripSplit(*split)
-        local, gathered_flat, gather_lists = make_buffers(split)
-        works = [None, None]
-        asm_done = [torch.cuda.Event(), torch.cuda.Event()]
-        asm_used = [False, False]
+                try:
+                    comm = sp.Comm(ids[0], rank, world, local_rank)
+                    comm.selftest(1 << 20, stream.cuda_stream)
+                except Exception as e:
+                    print("bench.py: rank %d: the library's communicator failed (%r); falling back to torch.distributed" % (rank, e), file=sys.stderr)
+                    ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:     # every rank takes the same way
+                transport = "torch (fallback: sdfr_comm_create or its self-test failed on some rank)"
+                if comm is not None:
+                    comm.close()
+                    comm = None
+        if comm is None:
+            side = torch.cuda.Stream()
+            r_asm = r_priv = None
+            if rank == 0:
+                r_asm = sp.SDFRenderer(local_rank)  # a handle bound to the side stream, for the assembly kernel
+                r_asm.setStream(side.cuda_stream)
+                r_priv = [make_renderer(rs[b]) for b in range(depth)]  # private strips: handles of their own, so that counters do not mix
+            works = [None] * depth
+            asm_done = [torch.cuda.Event() for _ in range(depth)]
+            asm_used = [False] * depth
+            local = gathered_flat = gather_lists = None
+
+        def set_split(sp_split):
+            nonlocal local, gathered_flat, gather_lists
+            for h_ in rr + (([r_asm] + r_priv) if (comm is None and rank == 0) else []):
+                h_.setStripSplit(*sp_split)
+            if comm is None:
+                torch.cuda.synchronize()
+                nb = sp.strip_buffer_bytes(W, H, world, wire_fmt, sp_split)
+                local = [torch.empty((nb,), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+                gathered_flat = [torch.empty((world, nb), dtype=torch.uint8, device="cuda") for _ in range(depth)] if rank == 0 else None
+                gather_lists = [list(g.unbind(0)) for g in gathered_flat] if rank == 0 else None
 
     def step(s):
         """Enqueue frame s; returns the handles that render it (their counters add up to this rank's share)."""
@@ -290,28 +463,31 @@ def main():
             r.setCamera(cam)
             r.render(None, W, H, out=image)
             return [r]
-        b = s & 1
+        b = s % depth
         h = rr[b]
         h.setParameters(stime)
         h.setCamera(cam)
+        if comm is not None:
+            h.renderGather(comm, W, H, out=images[b] if rank == 0 else None, fmt=img_fmt, wire=wire_fmt)
+            return [h]
         used = [h]
         with torch.cuda.stream(rs[b]):
             if works[b] is not None:
-                works[b].wait()                    # this frame's stream: local[b] is free once gather s-2 is done
+                works[b].wait()                    # this frame's stream: local[b] is free once the gather `depth` frames ago is done
             if rank == 0 and asm_used[b]:
-                rs[b].wait_event(asm_done[b])      # gathered_flat[b] is free once assembly s-2 is done
-            h.renderStrips(W, H, rank, world, local[b], fmt=sp.STRIP_RGB32F_A8)
+                rs[b].wait_event(asm_done[b])      # gathered_flat[b] is free once that frame's assembly is done
+            h.renderStrips(W, H, rank, world, local[b], fmt=wire_fmt)
             if rank == 0:
                 works[b] = dist.gather(local[b], gather_list=gather_lists[b], dst=0, async_op=True)
                 if split[0] > 0:  # after the gather was issued: the private strips render while the peers' strips travel
                     hp = r_priv[b]
                     hp.setParameters(stime)
                     hp.setCamera(cam)
-                    hp.renderPrivateStrips(W, H, images[b])
+                    hp.renderPrivateStrips(W, H, images[b], fmt=img_fmt)
                     used.append(hp)
                 with torch.cuda.stream(side):
                     works[b].wait()
-                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=sp.STRIP_RGB32F_A8)
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=wire_fmt)
                     asm_done[b].record(side)
                     asm_used[b] = True
             else:
@@ -324,14 +500,45 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if distributed:
+        # ---- how much of the frame should rank 0 keep for itself? ---------------------------------------
+        # Its own pixels never cross a link, and for N > 1 the frame rate may be bounded by what the peers
+        # push through their single link each.  Timed here, once: the pipeline itself with m = 0, 2, 4, ...
+        # of every 16 strips private to rank 0; every rank adopts the fastest (max over ranks of the time
+        # between two barriers).  A larger m must win by 3 % to be preferred.
+        if a.private_strips != "auto":
+            split = (max(0, min(SPLIT_PERIOD - 1, int(a.private_strips))), SPLIT_PERIOD)
+            set_split(split)
+            calibration = {"private_strips_of_16": split[0], "forced": True}
+        else:
+            trials = {}
+            best = None
+            for m in ((0,) if world == 1 and not a.force_distributed else (0, 2, 4, 6, 8)):
+                split = (m, SPLIT_PERIOD)
+                set_split(split)
+                for s in range(2):
+                    step(s)
+                fence()
+                t0c = time.perf_counter()
+                for s in range(6):
+                    step(s)
+                fence()
+                tm = torch.tensor([(time.perf_counter() - t0c) / 6 * 1e3], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                trials[m] = float(tm.item())
+                if best is None or trials[m] < trials[best] * 0.97:
+                    best = m
+            split = (best, SPLIT_PERIOD)
+            set_split(split)
+            calibration = {"private_strips_of_16": best, "forced": False, "ms_per_frame_by_private_strips": trials}
+
     for s in range(a.warmup):
         step(s)
     fence()
-    # rays are a property of the frames, independent of timing: count them outside the timed region
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for s in range(a.steps):
-        es = rs[s & 1] if distributed else stream
+        es = rs[s % depth] if distributed else stream
         ev[s][0].record(es)
         step(s)
         ev[s][1].record(es)
@@ -339,19 +546,33 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # per-frame ray counts of this rank (exact, from the kernels' counters), outside the timing
+    # rays are a property of the frames, independent of timing: counted outside the timed region, from
+    # the kernels' own counters; N > 1: the duration of this rank's k_pixel launch alone comes from a
+    # strips render without the gather
     rays_per_frame = []
     kernel_ms = []
+    scratch = None
     for k in range(min(SWEEP, a.steps)):
-        sts = [h_.getStats() for h_ in step(k)]
+        hs = step(k)
+        sts = [h_.getStats() for h_ in hs]
         rays_per_frame.append(sum(int(st.rays) for st in sts))
-        kernel_ms.append(sum(st.ms_gpu for st in sts))
+        if distributed and comm is not None:
+            if scratch is None:
+                scratch = torch.empty((sp.strip_buffer_bytes(W, H, world, wire_fmt, split),), dtype=torch.uint8, device="cuda")
+            hs[0].renderStrips(W, H, rank, world, scratch, fmt=wire_fmt)
+            kernel_ms.append(hs[0].getStats().ms_gpu)
+        else:
+            kernel_ms.append(sum(st.ms_gpu for st in sts))
     my_rays = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(a.steps))
     step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays_t = torch.tensor([my_rays], dtype=torch.float64, device="cuda")
+    per_rank = None
     if distributed:
+        every = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, torch.tensor([my_rays, elapsed], dtype=torch.float64, device="cuda"))
+        per_rank = [{"rank": i, "rays": float(v[0].item()), "seconds": float(v[1].item())} for i, v in enumerate(every)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -362,22 +583,23 @@ def main():
         last = a.steps - 1
         step(last)
         torch.cuda.synchronize()
-        got = images[last & 1 if distributed else 0].clone()
-        cam, stime = make_camera(last % SWEEP, W, H)
+        got = images[last % depth].clone()
+        cam, stime = cameras[last % SWEEP]
         r.setParameters(stime)
         r.setCamera(cam)
         ref = torch.empty_like(got)
-        r.render(None, W, H, out=ref)
+        r.render(None, W, H, out=ref, fmt=img_fmt)
         torch.cuda.synchronize()
-        verified = bool(torch.equal(got.view(torch.int32), ref.view(torch.int32)))
+        it = torch.int32 if img_fmt == sp.RGBA32F else torch.int16
+        verified = bool(torch.equal(got.view(it), ref.view(it)))
     elif a.verify and distributed:
         step(a.steps - 1)  # every rank takes part in the extra gather
         torch.cuda.synchronize()
 
     if rank == 0:
-        census = load_census()
+        census = load_census(a.config)
         out = {
-            "metric": "Mrays/s (primary+secondary), labyrinth scene, 3840x2160",
+            "metric": cfg["metric"],
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -390,43 +612,49 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "labyrinth %dx%d, iter_count %d, reference cost rules (max_cost 7, hard shadows), 16-frame fixed-seed camera sweep (seed 0x5DF00003), default variables" % (W, H, ITER_COUNT),
-                "schedule": "pixel" if schedule == sp.SCHEDULE_PIXEL else "wavefront",
+                "workload": cfg["workload"] % (W, H),
+                "baseline_config": a.config,
+                "schedule": schedule_name,
                 "parallelism": "strips%d" % world if distributed else "single",
-                "strip_calibration": calibration,
                 "rays_per_pixel": total_rays / a.steps / (W * H),
             },
         }
-        # roofline of the dominant kernel (the only kernel of the pixel schedule), N = 1 geometry
-        # kernel duration: HIP events on the launch stream.  N = 1: the pairs recorded around every
-        # step of the timed region (a step launches k_pixel + the 12-us counter fold and nothing
-        # else); N > 1: a step also gathers, so the handle's own events of the counting pass are used
+        if distributed:
+            out["config"].update({
+                "transport": ("sdfr_render_gather (RCCL ncclSend/ncclRecv inside libsdfr.so)" if comm is not None else "torch.distributed.gather: " + str(transport)),
+                "wire_format": "SDFR_STRIP_RGB16F_A8 (7 B/pixel)" if wire16 else "SDFR_STRIP_RGB32F_A8 (13 B/pixel)",
+                "image": "RGBA16F on rank 0 (the reference's render-target format, Postprocessing.cpp:23)" if wire16 else "RGBA32F on rank 0",
+                "frames_in_flight": depth,
+                "strip_calibration": calibration,
+                "per_rank": per_rank,
+            })
+        # roofline of the dominant kernel (k_pixel, the only kernel of the pixel schedule), this rank's
+        # launch.  Kernel duration: HIP events on the launch stream -- N = 1: the pairs recorded around
+        # every step of the timed region (a step launches k_pixel + the few-us counter fold and nothing
+        # else); N > 1: a step also gathers, so the handle's own events around a strips render are used
         stats_pass_ms = float(np.mean(kernel_ms))
         mean_kernel_ms = stats_pass_ms if distributed else float(np.mean(step_ms))
         mean_rays = float(np.mean(rays_per_frame))
         if census:
             flops_per_launch = census["flops_per_ray"] * mean_rays
             achieved = flops_per_launch / (mean_kernel_ms * 1e-3) / 1e12
-            traffic = None
-            pmc = None
-            try:
-                with open(PMC_FILE) as fh:
-                    pj = json.load(fh)
-                traffic = pj.get("hbm_bytes_per_launch")
-                for name, k in pj.get("kernels", {}).items():
-                    if "k_pixel" in name:
-                        # executed work (rocprofv3 --pmc over this same command, profiles/pmc_r01.json): the
-                        # census numerator above is algorithmic and includes evaluations the kernel culls
-                        pmc = {"valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"], "valu_lane_utilization": k["valu_lane_utilization"],
-                               "cycles_per_valu_instruction_per_simd": k["cycles_per_valu_inst_per_simd"], "waves_per_simd": k["avg_waves_per_simd"]}
-            except Exception:
-                pass
-            out["roofline"] = {
+            pmc = load_pmc(a.config, W, H, schedule_name) if not distributed else None
+            roof = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic,
-                "kernel_ms": mean_kernel_ms, "kernel_ms_counting_pass": stats_pass_ms, "flops_per_ray": census["flops_per_ray"], "pmc": pmc,
-                "note": "FP32 vector (VALU) issue bounds this path, not HBM or MFMA (SURVEY.md 8d); flops = oracle operation census",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                "kernel_ms": mean_kernel_ms, "kernel_ms_counting_pass": stats_pass_ms, "flops_per_ray": census["flops_per_ray"],
+                "numerator": "ALGORITHMIC: oracle operation census x rays of this launch; it counts every scene evaluation the reference makes, "
+                             "also those the kernel's bounding-volume tests skip, so `frac` is an algorithmic-equivalent rate, not VALU busy time",
+                "note": "FP32 vector (VALU) issue bounds this path, not HBM or MFMA (SURVEY.md 8d)",
             }
+            if pmc:
+                # executed work: lane-operations the VALU really issued (PMC) per second of THIS run's kernel time,
+                # against one lane-op per lane per cycle.  The PMC counts are a committed profile of this same command.
+                roof["executed"] = dict(pmc, lane_ops_per_s=pmc["executed_lane_ops_per_launch"] / (mean_kernel_ms * 1e-3),
+                                        peak_lane_ops_per_s=PEAK_VALU_LANE_OPS,
+                                        frac_executed=pmc["executed_lane_ops_per_launch"] / (mean_kernel_ms * 1e-3) / PEAK_VALU_LANE_OPS)
+                roof["traffic_source"] = pmc["source"]
+            out["roofline"] = roof
         bytes_per_launch = 16.0 * W * H / world
         out["roofline_hbm"] = {
             "bound": "hbm", "achieved": bytes_per_launch / (mean_kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -437,18 +665,14 @@ def main():
         out["host_enqueue_ms_per_step"] = enqueue_ms
         if verified is not None:
             out["verified"] = verified
-        if not distributed:
+        if not distributed and not a.no_second_pass:
             # Not the headline: the same sweep with TWO frames in flight (two handles on two streams),
             # measured after the timed region.  It shows how much of `ms_per_step` is the tail of a
-            # frame (the last few waves march their 256-step rays alone); `value` and `roofline` above
+            # frame (the last few waves march their long rays alone); `value` and `roofline` above
             # stay on one frame in flight, where a kernel's duration is its own.
             try:
                 s2 = torch.cuda.Stream()
-                r2 = sp.SDFRenderer(local_rank)
-                r2.initShader(SCENE)
-                r2.setLimits(iter_count=ITER_COUNT)
-                r2.setSchedule(schedule)
-                r2.setStream(s2.cuda_stream)
+                r2 = make_renderer(s2)
                 img2 = torch.empty_like(image)
                 pair = [(r, image), (r2, img2)]
 
@@ -473,7 +697,7 @@ def main():
                 out["two_frames_in_flight"] = {"error": repr(e)}
         if not distributed and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(a.config, W, H)
             except Exception as e:  # the bench line must still be printed
                 out["cpu_baseline"] = {"error": repr(e)}
         if saved_stdout is not None:
@@ -481,10 +705,18 @@ def main():
             os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
 
+    if distributed:
+        torch.cuda.synchronize()
+        dist.barrier()
+        for h_ in rr[1:]:
+            h_.close()
+        if comm is not None:
+            comm.close()
     r.close()
     if distributed:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -35,7 +35,8 @@ typedef enum sdfr_status
 	SDFR_ERR_NO_SCENE = -4,         /* render without a loaded scene: SDFRenderer::render returns false (SDFRenderer.cpp:70-73) */
 	SDFR_ERR_HIP = -5,
 	SDFR_ERR_NO_DEVICE = -6,
-	SDFR_ERR_COMPILE = -7 /* a run-time scene does not compile: sdfr_last_error holds the compiler's messages */
+	SDFR_ERR_COMPILE = -7, /* a run-time scene does not compile: sdfr_last_error holds the compiler's messages */
+	SDFR_ERR_COMM = -8     /* RCCL could not be loaded, or one of its calls failed: sdfr_comm_last_error / sdfr_last_error */
 } sdfr_status;
 
 /* ---- lifetime: SDFRenderer::init(Graphics&) (SDFRenderer.cpp:9-25) ----------------------- */
@@ -129,7 +130,12 @@ typedef enum sdfr_format
 	 * lossless -- rgb as three floats, then one byte per pixel for alpha, which is the tone-map flag
 	 * (pshader_sdf.hlsl:357-359, 0 or 1).  19 % fewer bytes through the inter-GPU gather; assembles
 	 * into an RGBA32F image. */
-	SDFR_STRIP_RGB32F_A8 = 2
+	SDFR_STRIP_RGB32F_A8 = 2,
+	/* strips only: the RGBA16F frame -- what the reference's render target stores (Postprocessing.cpp:23)
+	 * -- in 7 bytes per pixel: rgb as three halves (round to nearest even of the fp32 result), then one
+	 * byte per pixel for alpha.  Assembles into an RGBA16F image equal, bit for bit, to a direct
+	 * SDFR_RGBA16F render.  The smallest wire format: 58 MB per 3840x2160 frame. */
+	SDFR_STRIP_RGB16F_A8 = 3
 } sdfr_format;
 
 /* Render a width x height frame into `out` (device pointer if out_on_host == 0, else host).
@@ -158,6 +164,42 @@ int64_t sdfr_strip_buffer_bytes_split(int width, int height, int world, int form
 int sdfr_render_private_strips(sdfr_renderer *r, int width, int height, void *out_image, int format);
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format);
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format);
+
+/* ---- multi-GPU in the library itself: RCCL over xGMI (no reference counterpart --
+ *      the reference drives one adapter, Graphics.cpp:34).  One communicator per process and GPU
+ *      (sdfr_comm_create, from an id made on rank 0 and handed to the others by the caller's own
+ *      means), or one per device of a single process (sdfr_comm_create_all).  librccl.so is opened
+ *      on first use: the library has no load-time dependency on it.
+ *
+ *      sdfr_render_gather: every rank renders the shared strips of its rank (strip layout above, the
+ *      handle's strip split included) in `wire_format` into a buffer the handle owns; the peers
+ *      ncclSend theirs to rank 0, which ncclRecv's them (one group per frame, N - 1 messages on N - 1
+ *      different xGMI links), scatters them into `root_image` and -- with a strip split -- renders its
+ *      private strips straight into `root_image` meanwhile.  Transfer and assembly run on a stream of
+ *      the handle's own; the call returns once everything is enqueued and the handle's stream is made
+ *      to wait for it, so sdfr_sync (or any later work on that stream) sees the finished image.
+ *        image_format SDFR_RGBA32F needs a 32-bit wire format (SDFR_RGBA32F, SDFR_STRIP_RGB32F_A8),
+ *        image_format SDFR_RGBA16F a 16-bit one (SDFR_RGBA16F, SDFR_STRIP_RGB16F_A8);
+ *        root_image is ignored on the other ranks (may be NULL).
+ *      Every rank must call it with the same frame size, formats, strip split, and in the same order
+ *      when several handles share one communicator (two frames in flight: two handles, two streams).
+ *      sdfr_get_stats afterwards reports this rank's own share. -------------------------------------- */
+typedef struct sdfr_comm sdfr_comm;
+#define SDFR_COMM_ID_BYTES 128
+int sdfr_comm_unique_id(void *id_out);                      /* ncclGetUniqueId; id_out: SDFR_COMM_ID_BYTES bytes */
+int sdfr_comm_create(const void *id, int rank, int world, int device_ordinal, sdfr_comm **out); /* collective: ncclCommInitRank */
+int sdfr_comm_create_all(const int *device_ordinals, int n, sdfr_comm **out_n);                 /* one process: ncclCommInitAll */
+void sdfr_comm_destroy(sdfr_comm *c);
+int sdfr_comm_rank(const sdfr_comm *c);
+int sdfr_comm_world(const sdfr_comm *c);
+const char *sdfr_comm_last_error(const sdfr_comm *c);
+/* `bytes` bytes travel rank -> (rank + 1) % world -> ... on `hip_stream` (world = 1: to itself) and are
+ * compared at the destination: proves that the library, the communicator and the links work.  Blocking. */
+int sdfr_comm_selftest(sdfr_comm *c, size_t bytes, void *hip_stream);
+int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, void *root_image, int image_format, int wire_format);
+/* the same for the n handles / communicators of ONE process (sdfr_comm_create_all), rank i = index i */
+int sdfr_render_gather_all(sdfr_renderer *const *r, sdfr_comm *const *c, int n, int width, int height, void *root_image, int image_format,
+	int wire_format);
 
 /* ---- the consumer of the render target: HDR::process
  *      (Postprocessing.cpp:130-174; bloom.hlsl; pshader_hdr.hlsl).  scene = the RGBA16F frame of

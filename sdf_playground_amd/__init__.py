@@ -28,11 +28,13 @@ SCHEDULE_PIXEL = 1
 RGBA32F = 0
 RGBA16F = 1
 STRIP_RGB32F_A8 = 2  # strips only: rgb float triples + one flag byte per pixel (lossless, 13 B/pixel)
+STRIP_RGB16F_A8 = 3  # strips only: rgb half triples + one flag byte per pixel (the reference's RGBA16F target in 7 B/pixel)
+COMM_ID_BYTES = 128
 STRIP_ROWS = 8
 
 _STATUS = {
     0: "SDFR_OK", -1: "SDFR_ERR_INVALID_ARGUMENT", -2: "SDFR_ERR_UNKNOWN_SCENE", -3: "SDFR_ERR_UNKNOWN_VARIABLE",
-    -4: "SDFR_ERR_NO_SCENE", -5: "SDFR_ERR_HIP", -6: "SDFR_ERR_NO_DEVICE",
+    -4: "SDFR_ERR_NO_SCENE", -5: "SDFR_ERR_HIP", -6: "SDFR_ERR_NO_DEVICE", -7: "SDFR_ERR_COMPILE", -8: "SDFR_ERR_COMM",
 }
 
 
@@ -72,6 +74,8 @@ EXPORTED_SYMBOLS = [
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
     "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
+    "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_rank", "sdfr_comm_world",
+    "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all",
 ]
 
 _lib = None
@@ -145,6 +149,18 @@ def load_library():
     L.sdfr_get_timings.argtypes = [vp, ctypes.POINTER(_CTiming), ci]
     L.sdfr_postprocess.argtypes = [vp, ci, ci, vp, vp, vp]
     L.sdfr_selftest_math.argtypes = [vp, ci, cf, ctypes.POINTER(ctypes.c_uint64)]
+    L.sdfr_comm_unique_id.argtypes = [vp]
+    L.sdfr_comm_create.argtypes = [vp, ci, ci, ci, ctypes.POINTER(vp)]
+    L.sdfr_comm_create_all.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+    L.sdfr_comm_destroy.argtypes = [vp]
+    L.sdfr_comm_destroy.restype = None
+    L.sdfr_comm_rank.argtypes = [vp]
+    L.sdfr_comm_world.argtypes = [vp]
+    L.sdfr_comm_last_error.argtypes = [vp]
+    L.sdfr_comm_last_error.restype = ctypes.c_char_p
+    L.sdfr_comm_selftest.argtypes = [vp, ctypes.c_size_t, vp]
+    L.sdfr_render_gather.argtypes = [vp, vp, ci, ci, vp, ci, ci]
+    L.sdfr_render_gather_all.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, vp, ci, ci]
     _lib = L
     return L
 
@@ -404,6 +420,20 @@ class SDFRenderer:
                                                  ctypes.c_void_p(out.data_ptr()), fmt))
         return out
 
+    def renderGather(self, comm, width, height, out=None, fmt=RGBA32F, wire=None):
+        """Multi-GPU frame through the library's own RCCL gather (sdfr_render_gather): every rank renders
+        its strips, rank 0 receives them and assembles `out` (a device tensor of the full frame; None
+        on the other ranks).  wire: strip format on the links (default: the packed one that matches fmt)."""
+        if wire is None:
+            wire = STRIP_RGB32F_A8 if fmt == RGBA32F else STRIP_RGB16F_A8
+        ptr = None
+        if out is not None:
+            assert out.is_cuda and out.is_contiguous() and out.numel() == width * height * 4
+            assert out.element_size() == (4 if fmt == RGBA32F else 2)
+            ptr = ctypes.c_void_p(out.data_ptr())
+        self._check(self._L.sdfr_render_gather(self._h, comm._c, width, height, ptr, fmt, wire))
+        return out
+
     def getTimings(self):
         """GPUProfiler::getResults: {name: ms} of the last render and the last postprocess, in frame order."""
         buf = (_CTiming * 48)()
@@ -434,6 +464,48 @@ class SDFRenderer:
         s = Stats()
         self._check(self._L.sdfr_get_stats(self._h, ctypes.byref(s)))
         return s
+
+
+class Comm:
+    """One RCCL communicator per process and GPU (sdfr_comm_*).  Rank 0 makes the id with
+    Comm.unique_id() and hands it to the other ranks by any means (bench.py: torch.distributed
+    broadcast); creation is collective."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        L = load_library()
+        rc = L.sdfr_comm_unique_id(buf)
+        if rc != SDFR_OK:
+            raise SdfrError(rc, L.sdfr_comm_last_error(None).decode())
+        return bytes(buf.raw)
+
+    def __init__(self, uid, rank, world, device=0):
+        self._L = load_library()
+        self._c = ctypes.c_void_p()
+        assert len(uid) == COMM_ID_BYTES
+        rc = self._L.sdfr_comm_create(ctypes.c_char_p(uid), int(rank), int(world), int(device), ctypes.byref(self._c))
+        if rc != SDFR_OK:
+            raise SdfrError(rc, self._L.sdfr_comm_last_error(None).decode())
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    def selftest(self, nbytes=1 << 20, stream_handle=None):
+        """Ring exchange of nbytes over the communicator, compared at the destination (blocking)."""
+        rc = self._L.sdfr_comm_selftest(self._c, int(nbytes), ctypes.c_void_p(stream_handle))
+        if rc != SDFR_OK:
+            raise SdfrError(rc, self._L.sdfr_comm_last_error(self._c).decode())
+        return True
+
+    def close(self):
+        if self._c:
+            self._L.sdfr_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HDR:
@@ -508,6 +580,27 @@ def unpack_strip_host(packed, n):
     c = np.zeros((n, 4), np.float32)
     c[:, :3] = packed[:12 * n].view(np.float32).reshape(n, 3)
     c[:, 3] = packed[12 * n:13 * n].astype(np.float32)
+    return c
+
+
+def pack_strip16_host(compact_rgba):
+    """Host statement of SDFR_STRIP_RGB16F_A8: [n, 4] float32 (alpha 0 or 1) -> uint8 buffer of
+    (7 n + 3) // 4 * 4 bytes: n rgb half triples (round to nearest even), then n flag bytes."""
+    c = np.ascontiguousarray(compact_rgba, np.float32).reshape(-1, 4)
+    n = c.shape[0]
+    out = np.zeros(((7 * n + 3) // 4 * 4,), np.uint8)
+    with np.errstate(over="ignore"):
+        out[:6 * n] = np.ascontiguousarray(c[:, :3].astype(np.float16)).view(np.uint8).reshape(-1)
+    out[6 * n:7 * n] = (c[:, 3] != 0).astype(np.uint8)
+    return out
+
+
+def unpack_strip16_host(packed, n):
+    """Inverse of pack_strip16_host: -> [n, 4] float16 (the RGBA16F pixels)."""
+    packed = np.asarray(packed, np.uint8)
+    c = np.zeros((n, 4), np.float16)
+    c[:, :3] = packed[:6 * n].view(np.float16).reshape(n, 3)
+    c[:, 3] = packed[6 * n:7 * n].astype(np.float16)
     return c
 
 

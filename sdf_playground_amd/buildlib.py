@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdfr.so")
-SOURCES = ["sdfr_api.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_post.hip"]
+SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_post.hip"]
 ARCH = "gfx950"
 
 

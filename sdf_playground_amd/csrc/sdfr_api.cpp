@@ -3,12 +3,7 @@
 // Host logic only: handle state (scene, variable table, camera, limits), per-frame uniform
 // preparation, device buffers and launches.  All pixels are produced by the HIP kernels in
 // sdfr_kernels.hip; there is no CPU rendering path.
-#include "../../include/sdfr.h"
-
-#include "sdfr_hostframe.h"
-#include "sdfr_hostlib.h"
-#include "sdfr_jit.h"
-#include "sdfr_kernels.h"
+#include "sdfr_handle.h"
 
 #include <chrono>
 #include <cstdio>
@@ -27,59 +22,20 @@ static const char *k_driver_variables =
 	"VAR_debug_ny(min = -1, max = +1, step = 0.02) VAR_debug_nz(min = -1, max = +1, step = 0.02) "
 	"VAR_show_objects(min = 0, max = 1, step = 1, start = 1) VAR_debug_scale(min = 0.005, max = 2, step = 0.005, start = 0.2)";
 
-struct sdfr_renderer
-{
-	int device = 0;
-	hipStream_t stream = nullptr;
-	int scene = -1; // index of an ahead-of-time scene, or SDFR_SCENE_COUNT: `jit` holds a scene compiled at run time
-	JitScene jit;
-	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
-	bool profiling = false;
-	int tile_w_log2 = 3;
-	int priv_count = 0, priv_period = 1; // sdfr_set_strip_split
-	FrameU U;
-	host::ShaderVariableManager vars;
-	std::vector<std::string> scene_var_slots; // slot k of FrameU::scene_var <- this variable
-	mutable std::string error;
 
-	RenderTotals *d_totals = nullptr;
-	WavefrontWorkspace ws = {};
-	size_t wavefront_capacity = 0; // pixels the wavefront-only part of `ws` is allocated for
-	void *d_stage = nullptr; // staging image for host-destination renders
-	size_t stage_bytes = 0;
-	uint32_t *d_pstat = nullptr;
-	size_t pstat_bytes = 0;
-
-	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-	hipEvent_t ev_post[3] = {}; // before / between / after the two post-processing kernels
-	bool have_post = false;
-	double ms_setup = 0.0;      // host time of the last latch_frame (+ Scene::prepare of a run-time scene)
-	hipEvent_t ev_march[32] = {}, ev_shade[32] = {};
-	int last_rounds = 0;
-	bool have_render = false;
-	bool last_wavefront = false;
-	bool last_profiled = false;
-};
-
-static int fail(const sdfr_renderer *r, int code, const std::string &msg)
-{
-	if (r) r->error = msg;
-	return code;
-}
-static int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
-{
-	return fail(r, SDFR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define SDFR_HIP(call) \
-	do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(r, e_, #call); } while (0)
-
-// bytes of a compact image of `pixels` pixels (per rank, for the packed format padded to 4)
-static size_t image_bytes(size_t pixels, int format)
+namespace sdfr {
+size_t image_bytes(size_t pixels, int format)
 {
 	if (format == SDFR_RGBA32F) return pixels * 16;
 	if (format == SDFR_RGBA16F) return pixels * 8;
+	if (format == SDFR_STRIP_RGB16F_A8) return (pixels * 7 + 3) & ~(size_t)3;
 	return (pixels * 13 + 3) & ~(size_t)3;
 }
+bool is_wire_format(int format)
+{
+	return format == SDFR_RGBA32F || format == SDFR_RGBA16F || format == SDFR_STRIP_RGB32F_A8 || format == SDFR_STRIP_RGB16F_A8;
+}
+} // namespace sdfr
 
 static void free_workspace(sdfr_renderer *r)
 {
@@ -169,7 +125,7 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 	r->U.front = V3(f.x, f.y, f.z);
 	r->U.right = V3(rt.x, rt.y, rt.z);
 	r->U.top = V3(tp.x, tp.y, tp.z);
-	if (hipMalloc((void **)&r->d_totals, sizeof(RenderTotals)) != hipSuccess || hipEventCreate(&r->ev_begin) != hipSuccess ||
+	if (hipMalloc((void **)&r->d_totals, 2 * sizeof(RenderTotals)) != hipSuccess || hipEventCreate(&r->ev_begin) != hipSuccess ||
 		hipEventCreate(&r->ev_end) != hipSuccess)
 	{
 		delete r;
@@ -190,11 +146,16 @@ void sdfr_destroy(sdfr_renderer *r)
 	if (!r) return;
 	(void)hipSetDevice(r->device);
 	(void)hipStreamSynchronize(r->stream);
+	if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
 	free_workspace(r);
 	jit_unload(r->jit);
 	(void)hipFree(r->d_totals);
 	(void)hipFree(r->d_stage);
 	(void)hipFree(r->d_pstat);
+	(void)hipFree(r->d_wire);
+	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
+	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
+	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
 	(void)hipEventDestroy(r->ev_begin);
 	(void)hipEventDestroy(r->ev_end);
 	for (hipEvent_t e : r->ev_post) (void)hipEventDestroy(e);
@@ -464,7 +425,7 @@ int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format) { 
 int64_t sdfr_strip_buffer_bytes_split(int width, int height, int world, int format, int priv_count, int priv_period)
 {
 	const int64_t n = sdfr_strip_buffer_pixels_split(width, height, world, priv_count, priv_period);
-	if (n < 0 || (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8)) return -1;
+	if (n < 0 || !is_wire_format(format)) return -1;
 	return (int64_t)image_bytes((size_t)n, format);
 }
 
@@ -515,14 +476,15 @@ static int latch_frame(sdfr_renderer *r, int width, int height)
 	return SDFR_OK;
 }
 
-enum RenderMode { RENDER_FULL, RENDER_STRIPS, RENDER_PRIVATE };
+} // extern "C"
 
-static int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
-	RenderMode mode)
+int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
+	RenderMode mode, RenderTotals *totals)
 {
+	if (r && !totals) totals = r->d_totals;
 	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
 	const bool strips = mode == RENDER_STRIPS;
-	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && !(strips && format == SDFR_STRIP_RGB32F_A8))
+	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && !(strips && is_wire_format(format)))
 		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	if (mode == RENDER_PRIVATE && r->priv_count == 0) return SDFR_OK; // no private strips: nothing to render
 	if (world < 1 || rank < 0 || rank >= world) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad rank/world");
@@ -586,7 +548,7 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	}
 
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
-	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(r->d_totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
+	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;
 	if (rm.local_rows == 0) return SDFR_OK; // e.g. every strip of a small frame is private
 	{
@@ -595,26 +557,30 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 		rc = ensure_workspace(r, need, !pixel_schedule);
 	}
 	if (rc != SDFR_OK) return rc;
-	SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
+	if (!r->caller_times) SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->scene == SDFR_SCENE_COUNT) // scenes compiled at run time exist for the PIXEL schedule only
 	{
-		e = jit_launch_pixel(r->jit, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream);
+		e = jit_launch_pixel(r->jit, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream);
 		r->last_wavefront = false;
 	}
 	else if (r->schedule == SDFR_SCHEDULE_PIXEL)
 	{
-		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream);
+		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream);
 		r->last_wavefront = false;
 	}
 	else
 	{
-		e = launch_wavefront_schedule(r->scene, r->U, rm, d_out, format, d_pstat, r->d_totals, r->ws, r->stream, r->profiling ? r->ev_march : nullptr,
+		e = launch_wavefront_schedule(r->scene, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream, r->profiling ? r->ev_march : nullptr,
 			r->profiling ? r->ev_shade : nullptr, &r->last_rounds);
 		r->last_wavefront = true;
 		r->last_profiled = r->profiling;
 	}
 	if (e != hipSuccess) return hip_fail(r, e, "kernel launch");
-	SDFR_HIP(hipEventRecord(r->ev_end, r->stream));
+	if (!r->caller_times)
+	{
+		SDFR_HIP(hipEventRecord(r->ev_end, r->stream));
+		r->totals_parts = 1;
+	}
 	r->have_render = true;
 
 	if (out_on_host)
@@ -625,6 +591,8 @@ static int render_impl(sdfr_renderer *r, int width, int height, int rank, int wo
 	}
 	return SDFR_OK;
 }
+
+extern "C" {
 
 int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
 {
@@ -644,7 +612,7 @@ int sdfr_render_private_strips(sdfr_renderer *r, int width, int height, void *ou
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format)
 {
 	if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
-	if (format != SDFR_RGBA32F && format != SDFR_RGBA16F && format != SDFR_STRIP_RGB32F_A8) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+	if (!is_wire_format(format)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
 	SDFR_HIP(hipSetDevice(r->device));
 	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->priv_count, r->priv_period, r->stream);
 	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
@@ -698,12 +666,15 @@ int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out)
 	float ms = 0.f;
 	SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
 	out->ms_gpu = ms;
-	RenderTotals t;
-	SDFR_HIP(hipMemcpy(&t, r->d_totals, sizeof t, hipMemcpyDeviceToHost));
-	out->pixels = t.pixels;
-	out->rays = t.rays;
-	out->march_evals = t.march_evals;
-	out->hits = t.hits;
+	RenderTotals t[2];
+	SDFR_HIP(hipMemcpy(t, r->d_totals, sizeof t, hipMemcpyDeviceToHost));
+	for (int k = 0; k < r->totals_parts; ++k)
+	{
+		out->pixels += t[k].pixels;
+		out->rays += t[k].rays;
+		out->march_evals += t[k].march_evals;
+		out->hits += t[k].hits;
+	}
 	if (r->last_wavefront)
 	{
 		for (int i = 0; r->last_profiled && i < r->last_rounds && i < 16; ++i)

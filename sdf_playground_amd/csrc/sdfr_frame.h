@@ -127,6 +127,6 @@ SDF_HD uint32_t private_strip_count(uint32_t strips, int priv_count, int priv_pe
 	return (strips / (uint32_t)priv_period) * (uint32_t)priv_count + (rem < (uint32_t)priv_count ? rem : (uint32_t)priv_count);
 }
 
-enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1, FORMAT_STRIP_RGB32F_A8 = 2 };
+enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1, FORMAT_STRIP_RGB32F_A8 = 2, FORMAT_STRIP_RGB16F_A8 = 3 };
 
 } // namespace sdfr

@@ -1,0 +1,83 @@
+// sdfr_handle.h -- the renderer handle behind the C ABI (include/sdfr.h) and the helpers the
+// translation units that implement it share (sdfr_api.cpp: single-GPU entries; sdfr_comm.cpp:
+// the multi-GPU gather over RCCL).  Host code only.
+#pragma once
+#include "../../include/sdfr.h"
+
+#include "sdfr_hostframe.h"
+#include "sdfr_hostlib.h"
+#include "sdfr_jit.h"
+#include "sdfr_kernels.h"
+
+#include <string>
+#include <vector>
+
+struct sdfr_renderer
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int scene = -1; // index of an ahead-of-time scene, or SDFR_SCENE_COUNT: `jit` holds a scene compiled at run time
+	sdfr::JitScene jit;
+	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
+	bool profiling = false;
+	int tile_w_log2 = 3;
+	int priv_count = 0, priv_period = 1; // sdfr_set_strip_split
+	sdfr::FrameU U;
+	sdfr::host::ShaderVariableManager vars;
+	std::vector<std::string> scene_var_slots; // slot k of FrameU::scene_var <- this variable
+	mutable std::string error;
+
+	sdfr::RenderTotals *d_totals = nullptr; // [2]: counters of the last launch; [1] = the private strips of a gather (sdfr_comm.cpp)
+	int totals_parts = 1;             // how many of them the last render filled
+	sdfr::WavefrontWorkspace ws = {};
+	size_t wavefront_capacity = 0; // pixels the wavefront-only part of `ws` is allocated for
+	void *d_stage = nullptr; // staging image for host-destination renders
+	size_t stage_bytes = 0;
+	uint32_t *d_pstat = nullptr;
+	size_t pstat_bytes = 0;
+
+	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+	hipEvent_t ev_post[3] = {}; // before / between / after the two post-processing kernels
+	bool have_post = false;
+	double ms_setup = 0.0;      // host time of the last latch_frame (+ Scene::prepare of a run-time scene)
+	hipEvent_t ev_march[32] = {}, ev_shade[32] = {};
+	int last_rounds = 0;
+	bool have_render = false;
+	bool last_wavefront = false;
+	bool last_profiled = false;
+
+	// multi-GPU gather (sdfr_comm.cpp): send / receive / assembly run on a stream of their own so
+	// that the root's private strips render while the peers' strips travel
+	hipStream_t comm_stream = nullptr;
+	hipEvent_t ev_strips = nullptr, ev_gathered = nullptr;
+	void *d_wire = nullptr;    // this rank's compact strips; on the root: world x that, slot 0 = its own
+	size_t wire_bytes = 0;
+	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
+};
+
+static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)
+{
+	if (r) r->error = msg;
+	return code;
+}
+static inline int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
+{
+	return fail(r, SDFR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SDFR_HIP(call) \
+	do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(r, e_, #call); } while (0)
+
+namespace sdfr {
+
+enum RenderMode { RENDER_FULL, RENDER_STRIPS, RENDER_PRIVATE };
+
+// bytes of a compact image of `pixels` pixels (the packed strip formats are padded to 4)
+size_t image_bytes(size_t pixels, int format);
+bool is_wire_format(int format);
+
+// one launch of the handle's scene over the rows `mode` selects (sdfr_api.cpp).  `totals` receives
+// the launch's counters (nullptr: the handle's d_totals).
+int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
+	RenderMode mode, RenderTotals *totals = nullptr);
+
+} // namespace sdfr

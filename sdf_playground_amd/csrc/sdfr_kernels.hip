@@ -374,8 +374,8 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 // ---- strip assembly on the root (multi-GPU) ---------------------------------------------------------
 // gathered[rank][local pixel] -> image[global pixel].  One block row per image row (blockIdx.y), so
 // the strip arithmetic is wave-uniform and there is no per-pixel division; one 16-byte store per
-// pixel.  RGBA32F / RGBA16F strips are copied; packed strips (12-byte rgb triples, then one flag
-// byte per pixel, per rank) expand to RGBA32F.
+// pixel.  RGBA32F / RGBA16F strips are copied; packed strips (12-byte float or 6-byte half rgb
+// triples, then one flag byte per pixel, per rank) expand to RGBA32F / RGBA16F.
 __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, int world, size_t strip_pixels, const uint32_t *gathered,
 	uint32_t *image, int format, int priv_count, int priv_period)
 {
@@ -397,6 +397,15 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, 
 		const unsigned char *base = reinterpret_cast<const unsigned char *>(gathered) + (size_t)rank * packed_rank_bytes;
 		const uint32_t *rgb = reinterpret_cast<const uint32_t *>(base) + 3 * lpix;
 		reinterpret_cast<uint4 *>(image)[g] = make_uint4(rgb[0], rgb[1], rgb[2], base[12 * strip_pixels + lpix] ? 0x3f800000u : 0u);
+	}
+	else if (format == FORMAT_STRIP_RGB16F_A8)
+	{
+		// 6-byte rgb half triples, then one flag byte per pixel, per rank -> RGBA16F (alpha 1.0 = 0x3c00)
+		const size_t packed_rank_bytes = (7 * strip_pixels + 3) & ~(size_t)3;
+		const unsigned char *base = reinterpret_cast<const unsigned char *>(gathered) + (size_t)rank * packed_rank_bytes;
+		const unsigned short *rgb = reinterpret_cast<const unsigned short *>(base) + 3 * lpix;
+		const uint32_t a = base[6 * strip_pixels + lpix] ? 0x3c00u : 0u;
+		reinterpret_cast<uint2 *>(image)[g] = make_uint2((uint32_t)rgb[0] | ((uint32_t)rgb[1] << 16), (uint32_t)rgb[2] | (a << 16));
 	}
 	else if (format == FORMAT_RGBA32F)
 	{

@@ -81,6 +81,16 @@ __device__ __forceinline__ void store_pixel(void *out, int format, uint32_t pid,
 		rgb[2] = c.z;
 		reinterpret_cast<unsigned char *>(out)[12 * (size_t)n_pixels + pid] = c.w != 0.f ? 1 : 0;
 	}
+	else if (format == FORMAT_STRIP_RGB16F_A8)
+	{
+		// what the reference's R16G16B16A16_FLOAT target holds, in 7 bytes per pixel for the inter-GPU
+		// gather: rgb as three halves (round to nearest even), alpha (0 or 1) as one byte
+		unsigned short *rgb = reinterpret_cast<unsigned short *>(out) + 3 * (size_t)pid;
+		rgb[0] = __builtin_bit_cast(unsigned short, (_Float16)c.x);
+		rgb[1] = __builtin_bit_cast(unsigned short, (_Float16)c.y);
+		rgb[2] = __builtin_bit_cast(unsigned short, (_Float16)c.z);
+		reinterpret_cast<unsigned char *>(out)[6 * (size_t)n_pixels + pid] = c.w != 0.f ? 1 : 0;
+	}
 	else
 	{
 		// round-to-nearest-even conversions (v_cvt_f16_f32), two halves per dword

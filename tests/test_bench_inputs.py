@@ -33,5 +33,11 @@ def test_census_file_matches_workload():
     import bench
 
     with open(bench.CENSUS_FILE) as fh:
-        c = json.load(fh)["labyrinth_4k_iter256"]
+        census = json.load(fh)
+    c = census["labyrinth_4k_iter256"]
     assert 5e3 < c["flops_per_ray"] < 5e4 and 1.0 < c["rays_per_pixel"] < 3.0
+    # one entry per BASELINE configuration, each naming its workload
+    for k, cfg in bench.CONFIGS.items():
+        e = census[cfg["key"]]
+        assert e["config"] == k and e["workload"] == cfg["workload"] % (cfg["width"], cfg["height"]) and e["flops_per_ray"] > 500
+        assert bench.load_census(k) == e

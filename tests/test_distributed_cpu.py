@@ -1,5 +1,5 @@
 """CPU tier, world_size = 2, gloo: the multi-rank path of bench.py -- 8-row strips dealt
-round-robin over ranks, one gather to rank 0, scatter into the image.  On the
+round-robin over ranks, every peer's strips sent to rank 0, scattered into the image.  On the
 CPU the strips are rendered by the oracle (there is no GPU here); the partition, the gather
 and the assembly are the code the GPU path uses (sdf_playground_amd strip helpers)."""
 import os
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, wire):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,28 +43,39 @@ def _worker(rank, world, port, out_path):
     for row in rows:
         strip = row // sp.STRIP_ROWS
         local[(strip // world) * sp.STRIP_ROWS + row % sp.STRIP_ROWS] = full[row]
-    # strips travel packed (13 bytes per pixel, uint8 tensors) exactly as in bench.py
-    t = torch.from_numpy(sp.pack_strip_host(local.reshape(n, 4)))
+    # strips travel packed (uint8 buffers) exactly as on the GPUs: 13 bytes per pixel (fp32, lossless) or
+    # 7 (the reference's RGBA16F target); the transfer is the pattern of sdfr_render_gather: every peer
+    # sends its buffer to rank 0, which receives them into consecutive slots (slot 0 = its own strips)
+    pack, unpack = (sp.pack_strip_host, sp.unpack_strip_host) if wire == "f32" else (sp.pack_strip16_host, sp.unpack_strip16_host)
+    t = torch.from_numpy(pack(local.reshape(n, 4)))
     if rank == 0:
-        gathered = [torch.empty_like(t) for _ in range(world)]
-        dist.gather(t, gather_list=gathered, dst=0)
-        unpacked = np.stack([sp.unpack_strip_host(g.numpy(), n) for g in gathered])
+        gathered = [t] + [torch.empty_like(t) for _ in range(1, world)]
+        reqs = [dist.irecv(gathered[p], src=p) for p in range(1, world)]
+        for q in reqs:
+            q.wait()
+        unpacked = np.stack([unpack(g.numpy(), n) for g in gathered])
         img = sp.assemble_strips_host(W, H, world, unpacked)
         np.save(out_path, img)
     else:
-        dist.gather(t, dst=0)
+        dist.send(t, dst=0)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_two_rank_strip_gather_matches_single_rank(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,wire", [(2, "f32"), (2, "f16")])
+def test_two_rank_strip_gather_matches_single_rank(oracle, tmp_path, world, wire):
     out_path = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_path, wire), nprocs=world, join=True)
     img = np.load(out_path)
     f = oracle.default_frame("labyrinth", W, H, stime=0.5)
     ref, _, _ = oracle.render("labyrinth", f)
-    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    if wire == "f32":
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    else:  # the RGBA16F target: the fp32 result rounded to nearest even (Postprocessing.cpp:23)
+        assert img.dtype == np.float16
+        with np.errstate(over="ignore"):
+            assert np.array_equal(img.view(np.uint16), ref.astype(np.float16).view(np.uint16))
+        assert np.array_equal(img.view(np.uint16), oracle.float_to_half(ref).view(np.uint16))
 
 
 def test_strip_partition_covers_every_row_once():

@@ -26,20 +26,36 @@ def test_bench_single_rank_line():
     d = _run([])
     assert d["verified"] is True and d["n_gpus"] == 1 and d["steps"] == 7 and d["unit"] == "Mrays/s"
     assert d["value"] > 0 and d["roofline"]["bound"] == "valu" and d["roofline"]["kernel_ms"] > 0
-    assert d["config"]["parallelism"] == "single"
+    assert d["config"]["parallelism"] == "single" and d["config"]["baseline_config"] == "3"
+    assert "two_frames_in_flight" in d and "two_frames_in_flight" not in _run(["--no-second-pass"])
 
 
-def test_bench_strip_pipeline_assembles_the_same_image():
-    d = _run(["--force-distributed"])
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+@pytest.mark.parametrize("wire", ["f16", "f32"])
+def test_bench_strip_pipeline_assembles_the_same_image(transport, wire):
+    """the N > 1 pipeline forced onto one rank: through the library's own RCCL gather
+    (sdfr_render_gather) and through torch.distributed.gather, both wire formats"""
+    d = _run(["--force-distributed", "--transport", transport, "--wire", wire])
     assert d["verified"] is True
-    assert d["config"]["parallelism"] == "strips1" and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == "strips1" and d["scaling"] == "strong" and d["n_gpus"] == 1
+    assert d["config"]["transport"].startswith("sdfr_render_gather" if transport == "rccl" else "torch.distributed.gather: torch")
+    assert ("RGB16F" in d["config"]["wire_format"]) == (wire == "f16")
     cal = d["config"]["strip_calibration"]
-    assert cal["t_full_ms"] > 0 and cal["t_gather_ms"] > 0 and 0 <= cal["private_strips_of_16"] < 16
+    assert 0 <= cal["private_strips_of_16"] < 16 and all(v > 0 for v in cal["ms_per_frame_by_private_strips"].values())
+    assert len(d["config"]["per_rank"]) == 1 and d["config"]["per_rank"][0]["rays"] > 0
 
 
-def test_bench_strip_pipeline_with_private_strips():
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_bench_strip_pipeline_with_private_strips(transport):
     """rank 0 keeps 5 of every 16 strips for itself (rendered straight into the image, never gathered)"""
-    d = _run(["--force-distributed", "--private-strips", "5"])
+    d = _run(["--force-distributed", "--private-strips", "5", "--transport", transport])
     assert d["verified"] is True and d["config"]["strip_calibration"]["private_strips_of_16"] == 5
     # same frames, same rays as the plain pipeline
     assert abs(d["config"]["rays_per_pixel"] - _run(["--force-distributed", "--private-strips", "0"])["config"]["rays_per_pixel"]) < 1e-12
+
+
+def test_bench_other_configurations_run():
+    """--config 2 (cube_sea as worded): its own metric name, census and workload text"""
+    d = _run(["--config", "2"])
+    assert d["verified"] is True and d["config"]["baseline_config"] == "2" and "cube_sea" in d["metric"]
+    assert d["roofline"]["flops_per_ray"] > 1000 and "ALGORITHMIC" in d["roofline"]["numerator"]

@@ -1,0 +1,144 @@
+"""GPU tier: the library's own multi-GPU path (sdfr_comm_* / sdfr_render_gather, RCCL inside
+libsdfr.so) as far as one GPU can exercise it -- a real RCCL communicator of world 1 (library
+loaded, ncclCommInitRank, a grouped send / receive to itself), the gathered frame against a direct
+render for every image / wire format pair and with a private-strip split, counters included -- and
+the new 7-byte wire format at world 2 / 3 / 8 emulated on one GPU (render every rank's strips, then
+assemble), which is the layout sdfr_render_gather moves."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 200, 139  # ragged last strip
+
+
+@pytest.fixture(scope="module")
+def comm():
+    import sdf_playground_amd as sp
+
+    c = sp.Comm(sp.Comm.unique_id(), 0, 1, 0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def scene_renderer():
+    import sdf_playground_amd as sp
+
+    r = sp.SDFRenderer(0)
+    r.initShader("labyrinth")
+    r.setParameters(0.75)
+    r.setLimits(iter_count=160)
+    cam = sp.Camera()
+    cam.SetEye((1.2, 5.0, 0.4))
+    cam.SetDirection((0.9, -0.35, 0.3))
+    cam.SetAspect(W / H)
+    r.setCamera(cam)
+    yield r
+    r.close()
+
+
+def test_communicator_self_test(comm):
+    assert (comm.rank, comm.world) == (0, 1)
+    assert comm.selftest(1 << 20)
+    assert comm.selftest(12345)
+
+
+@pytest.mark.parametrize("split", [(0, 1), (5, 16), (3, 4)])
+def test_render_gather_equals_direct_render(scene_renderer, comm, split):
+    import torch
+    import sdf_playground_amd as sp
+
+    r = scene_renderer
+    full32 = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    r.render(None, W, H, out=full32)
+    ref = r.getStats()
+    full16 = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+    r.render(None, W, H, out=full16, fmt=sp.RGBA16F)
+    r.sync()
+    r.setStripSplit(*split)
+    for fmt, wire, want, it in ((sp.RGBA32F, sp.STRIP_RGB32F_A8, full32, torch.int32), (sp.RGBA32F, sp.RGBA32F, full32, torch.int32),
+                                (sp.RGBA16F, sp.STRIP_RGB16F_A8, full16, torch.int16), (sp.RGBA16F, sp.RGBA16F, full16, torch.int16)):
+        out = torch.full((H, W, 4), -3.0, dtype=want.dtype, device="cuda")
+        for _ in range(2):  # twice: buffers are reused
+            r.renderGather(comm, W, H, out=out, fmt=fmt, wire=wire)
+        r.sync()
+        assert torch.equal(out.view(it), want.view(it)), (fmt, wire, split)
+        s = r.getStats()
+        assert (s.pixels, s.rays, s.march_evals, s.hits) == (ref.pixels, ref.rays, ref.march_evals, ref.hits), (fmt, wire, split)
+    # mismatched pairs are refused, nothing is enqueued
+    with pytest.raises(sp.SdfrError):
+        r.renderGather(comm, W, H, out=full32, fmt=sp.RGBA32F, wire=sp.STRIP_RGB16F_A8)
+    with pytest.raises(sp.SdfrError):
+        r.renderGather(comm, W, H, out=None, fmt=sp.RGBA32F, wire=sp.RGBA32F)  # rank 0 needs an image
+
+
+def test_two_handles_share_one_communicator(comm):
+    """two frames in flight: two handles on two streams alternate over one communicator"""
+    import torch
+    import sdf_playground_amd as sp
+
+    hs, streams, outs, refs = [], [], [], []
+    for k in range(2):
+        st = torch.cuda.Stream()
+        h = sp.SDFRenderer(0)
+        h.initShader("fractal")
+        h.setStream(st.cuda_stream)
+        hs.append(h)
+        streams.append(st)
+    cam = sp.Camera()
+    cam.SetAspect(W / H)
+    for k in range(6):
+        h = hs[k & 1]
+        h.setParameters(0.1 * k)
+        h.setCamera(cam)
+        out = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+        h.renderGather(comm, W, H, out=out, fmt=sp.RGBA16F)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for k in range(6):
+        hs[0].setParameters(0.1 * k)
+        ref = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+        hs[0].render(cam, W, H, out=ref, fmt=sp.RGBA16F)
+        hs[0].sync()
+        assert torch.equal(outs[k].view(torch.int16), ref.view(torch.int16)), k
+    for h in hs:
+        h.close()
+
+
+@pytest.mark.parametrize("world,split", [(2, (0, 1)), (3, (0, 1)), (8, (0, 1)), (4, (5, 16))])
+def test_half_wire_format_emulated_worlds(scene_renderer, world, split):
+    """SDFR_STRIP_RGB16F_A8 strips of `world` ranks assemble to the bits of a direct RGBA16F render;
+    the host (numpy) statement of the format agrees byte for byte."""
+    import torch
+    import sdf_playground_amd as sp
+
+    r = scene_renderer
+    full32 = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    r.render(None, W, H, out=full32)
+    full16 = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+    r.render(None, W, H, out=full16, fmt=sp.RGBA16F)
+    r.sync()
+    assert torch.equal(full16, full32.to(torch.float16))  # the fp16 target is the rounded fp32 result (SURVEY.md a-T.12)
+    r.setStripSplit(*split)
+    n = sp.strip_buffer_pixels(W, H, world, split)
+    nb = sp.strip_buffer_bytes(W, H, world, sp.STRIP_RGB16F_A8, split)
+    assert nb == (7 * n + 3) // 4 * 4
+    for schedule in (1, 0):
+        r.setSchedule(schedule)
+        packed = torch.full((world, nb), 0x5A, dtype=torch.uint8, device="cuda")
+        plain = torch.empty((world, n, 4), dtype=torch.float32, device="cuda")
+        for rank in range(world):
+            r.renderStrips(W, H, rank, world, packed[rank], fmt=sp.STRIP_RGB16F_A8)
+            r.renderStrips(W, H, rank, world, plain[rank], fmt=sp.RGBA32F)
+        out = torch.full((H, W, 4), -3.0, dtype=torch.float16, device="cuda")
+        r.renderPrivateStrips(W, H, out, fmt=sp.RGBA16F)
+        r.assembleStrips(W, H, world, packed, out, fmt=sp.STRIP_RGB16F_A8)
+        r.sync()
+        assert torch.equal(out.view(torch.int16), full16.view(torch.int16)), (schedule, world, split)
+        for rank in range(world):
+            host = sp.pack_strip16_host(plain[rank].cpu().numpy())
+            got = packed[rank].cpu().numpy()
+            assert np.array_equal(host[:7 * n], got[:7 * n]), rank
+            assert np.array_equal(sp.unpack_strip16_host(got, n).view(np.uint16), plain[rank].to(torch.float16).cpu().numpy().view(np.uint16))
+    r.setSchedule(1)

@@ -1,6 +1,10 @@
-"""Operation census of the bench workload with the counting build of the oracle
-(oracle/liboracle_census.so): algorithmic flops per ray = the roofline numerator.
-Writes profiles/census_r01.json.  Sample: all 16 sweep frames, every 16th pixel in x and y."""
+"""Operation census of the bench workloads with the counting build of the oracle
+(oracle/liboracle_census.so): algorithmic flops per ray = the roofline numerator of bench.py.
+Writes profiles/census_<round>.json, one entry per BASELINE configuration (bench.CONFIGS).
+Sample: all 16 sweep frames, every STEPth pixel in x and y.
+
+    python tools/make_census.py [config ...]      (default: every configuration)
+"""
 import json
 import os
 import sys
@@ -13,22 +17,29 @@ import bench
 from oracle import pyoracle as po
 
 po.build(census=True, ref=False)
-STEP = 16
-tot = np.zeros(4, np.float64)
-flops = transc = 0
-for k in range(bench.SWEEP):
-    eye, direction, stime = bench.sweep_camera(k)
-    basis = po.camera_direction(eye, direction, np.float32(bench.sp.to_radian(60.0)), np.float32(bench.WIDTH) / np.float32(bench.HEIGHT))
-    f = po.default_frame(bench.SCENE, bench.WIDTH, bench.HEIGHT, basis=basis, stime=stime)
-    f.iter_count = bench.ITER_COUNT
-    _, t, fl, tr = po.census(bench.SCENE, f, step=(STEP, STEP))
-    tot += t.astype(np.float64)
-    flops += fl
-    transc += tr
-px, rays, evals, hits = tot
-out = {
-    "labyrinth_4k_iter256": {
-        "sample": "16 sweep frames, every %dth pixel in x and y (%d pixels)" % (STEP, px),
+STEP = {"2": 8}  # 1920x1080: a denser sample for a similar pixel count
+configs = sys.argv[1:] or sorted(bench.CONFIGS)
+try:
+    with open(bench.CENSUS_FILE) as fh:
+        out = json.load(fh)
+except Exception:
+    out = {}
+for c in configs:
+    cfg = bench.CONFIGS[c]
+    step = STEP.get(c, 16)
+    tot = np.zeros(4, np.float64)
+    flops = transc = 0
+    for k in range(bench.SWEEP):
+        f = bench.oracle_frame(po, k, cfg["width"], cfg["height"], c)
+        _, t, fl, tr = po.census(cfg["scene"], f, step=(step, step))
+        tot += t.astype(np.float64)
+        flops += fl
+        transc += tr
+    px, rays, evals, hits = tot
+    out[cfg["key"]] = {
+        "config": c,
+        "workload": cfg["workload"] % (cfg["width"], cfg["height"]),
+        "sample": "16 sweep frames, every %dth pixel in x and y (%d pixels)" % (step, px),
         "counting_rule": "+ - * / sqrt rsqrt floor round min max compare select = 1, fma = 2, transcendental (sin cos atan2 exp2 log2) = 1, abs/neg = 0",
         "flops_per_ray": flops / rays,
         "flops_per_pixel": flops / px,
@@ -38,8 +49,7 @@ out = {
         "hits_per_ray": hits / rays,
         "flops_per_scene_eval_all_in": flops / (evals + 4 * hits),
     }
-}
+    print(c, json.dumps(out[cfg["key"]], indent=1), flush=True)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-with open(os.path.join(ROOT, "profiles", "census_r01.json"), "w") as fh:
+with open(bench.CENSUS_FILE, "w") as fh:
     json.dump(out, fh, indent=1)
-print(json.dumps(out, indent=1))
