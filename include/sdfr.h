@@ -51,6 +51,9 @@ int sdfr_set_stream(sdfr_renderer *r, void *hip_stream);
  *      Names are the reference's file stems without "sdf_scene_". ------------------------------ */
 int sdfr_scene_count(void);
 const char *sdfr_scene_name(int index);
+/* besides the listed names: "debug_materials", the library's own diagnostic scene (four objects wearing
+ * the driver's MATERIAL_ITER / PLAIN / NORMAL1 / NORMAL2 views, pshader_sdf.hlsl:430-455, which no
+ * reference scene emits; not part of the reference's scene list, hence not counted above) */
 int sdfr_load_scene(sdfr_renderer *r, const char *name);
 const char *sdfr_current_scene(const sdfr_renderer *r);
 /* Compile a scene from source text at run time -- the reference's edit-and-reload workflow

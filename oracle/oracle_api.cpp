@@ -19,6 +19,7 @@
 #include "scenes2.h"
 #include "scenes3.h"
 #include "scenes4.h"
+#include "test_scenes.h"
 
 #include <atomic>
 #include <cstdio>
@@ -115,9 +116,21 @@ const std::vector<SceneEntry> &scenes()
 	return table;
 }
 
+// scenes that exist for tests only (test_scenes.h): found by name, not part of the reference's list
+const std::vector<SceneEntry> &test_scenes()
+{
+	static const std::vector<SceneEntry> table = {
+		{"debug_materials", "", {}, &ps_main<SceneDebugMaterials>},
+	};
+	return table;
+}
+
 const SceneEntry *find_scene(const char *name)
 {
 	for (const auto &s : scenes())
+		if (strcmp(s.name, name) == 0)
+			return &s;
+	for (const auto &s : test_scenes())
 		if (strcmp(s.name, name) == 0)
 			return &s;
 	return nullptr;

@@ -176,8 +176,8 @@ int sdfr_set_stream(sdfr_renderer *r, void *hip_stream)
 	return SDFR_OK;
 }
 
-int sdfr_scene_count(void) { return SDFR_SCENE_COUNT; }
-const char *sdfr_scene_name(int index) { return scene_name(index); }
+int sdfr_scene_count(void) { return SDFR_PUBLIC_SCENE_COUNT; }
+const char *sdfr_scene_name(int index) { return index >= 0 && index < SDFR_PUBLIC_SCENE_COUNT ? scene_name(index) : nullptr; }
 
 // rebuild the variable table like SDFRenderer::initShader (SDFRenderer.cpp:35-47): clear, then
 // collect the tags of the driver and of the scene text
@@ -649,6 +649,17 @@ int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mis
 	*mismatches = h;
 	return SDFR_OK;
 }
+
+#ifdef SDFR_WAVE_TRACE
+// developer build only (tools/wave_trace.py): the per-block records of the last pixel-schedule launch
+int sdfr_debug_read_partials(sdfr_renderer *r, void *host, size_t records)
+{
+	if (!r || !host) return SDFR_ERR_INVALID_ARGUMENT;
+	SDFR_HIP(hipStreamSynchronize(r->stream));
+	SDFR_HIP(hipMemcpy(host, r->ws.partials, records * sizeof(RenderTotals), hipMemcpyDeviceToHost));
+	return SDFR_OK;
+}
+#endif
 
 int sdfr_sync(sdfr_renderer *r)
 {

@@ -127,7 +127,11 @@ bool jit_compile_code(const std::string &arch_name, const std::string &name, con
 	const std::string arch = "--offload-arch=" + arch_name;
 	const std::string inc = "-I" + header_dir();
 	const std::string block = "-DSDFR_PIXEL_BLOCK=" + std::to_string(pixel_block_threads()); // must match the launch
-	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", inc.c_str(), block.c_str()};
+	// sqrt1 / rcp1 / div_c are exact only on verified domains (sdfr_math.h), which the built-in scenes are
+	// checked against and a user's text is not: run-time scenes get the plain IEEE forms unless the text
+	// opts in by containing the token SDFR_FAST_EXACT_MATH (say, in a comment)
+	const char *math = scene_source.find("SDFR_FAST_EXACT_MATH") != std::string::npos ? "-DSDFR_FAST_EXACT_MATH=1" : "-DSDFR_SAFE_MATH=1";
+	const char *opts[] = {arch.c_str(), "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", inc.c_str(), block.c_str(), math};
 	rc = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
 	size_t log_bytes = 0;
 	rtc.log_size(prog, &log_bytes);

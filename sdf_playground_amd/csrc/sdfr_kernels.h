@@ -40,6 +40,9 @@ hipError_t launch_postprocess(int width, int height, const void *scene16, void *
 
 hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatches, hipStream_t stream);
 
+// wavefront schedule, scene-independent start of a frame: primary rays, empty queues, round-0 list
+hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_work, const WavefrontWorkspace &ws, uint32_t *pixel_stats, hipStream_t stream);
+
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream);
 
 int pixel_block_threads(); // block size of the pixel kernels (partials are sized by it)

@@ -30,11 +30,6 @@
 
 namespace sdfr {
 
-// refill a march wave once this many lanes are idle (or when all are)
-#define SDFR_REFILL_THRESHOLD 16
-// list entries a march wave claims per atomic
-#define SDFR_GRAB 128
-
 uint32_t launch_work_items(int width, const RowMap &rm)
 {
 	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
@@ -42,18 +37,10 @@ uint32_t launch_work_items(int width, const RowMap &rm)
 	const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
 	return tiles_x * tiles_y * 64u;
 }
-static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_work_items(U.width, rm); }
 
 // =================================================================================================
-// PIXEL schedule (body: sdfr_pixel_kernel.h)
+// kernels that do not depend on the scene (the per-scene ones: sdfr_kernels_group.hip)
 // =================================================================================================
-template <class Scene, bool DBG>
-__global__ SDFR_PIXEL_KERNEL_ATTRS void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)
-{
-	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap);
-}
-
 // Folds the per-block partial sums of a pixel-schedule launch (one 32-byte record per wave: 4 MB
 // at 4K) into the render totals, which the pixel kernel has cleared: a few blocks, each keeping
 // several independent loads in flight per thread, then ONE set of four atomics per block.
@@ -101,14 +88,8 @@ hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks,
 	return hipGetLastError();
 }
 
-// =================================================================================================
-// WAVEFRONT schedule
-// =================================================================================================
-// march result fields
-enum { RS_STATUS = 0, RS_T, RS_D, RS_NX, RS_NY, RS_NZ, RS_COUNT };
-// counters[]: [r] = size of round r's list (r = 0..16); [32 + r] = march cursor of round r
+// march result fields, list counters: see sdfr_kernels_group.hip
 enum { CNT_ROUND0 = 0 };
-
 
 // ---- k_init: primary rays, empty queues, cleared accumulators, round-0 list ---------------------
 __global__ __launch_bounds__(SDFR_BLOCK) void k_init(FrameU U, RowMap rm, uint32_t n_work, WavefrontWorkspace ws, uint32_t *pixel_stats)
@@ -145,230 +126,10 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_init(FrameU U, RowMap rm, uint32
 	}
 }
 
-// ---- k_march ----------------------------------------------------------------------------------------
-enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_GRAD0 = 2, LANE_GRAD1 = 3, LANE_GRAD2 = 4 };
-
-template <class Scene, bool DBG>
-__global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
-	const uint32_t *__restrict__ n_ptr, uint32_t *cursor, uint32_t *pixel_stats, RenderTotals *totals)
+hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_work, const WavefrontWorkspace &ws, uint32_t *pixel_stats, hipStream_t stream)
 {
-	const uint32_t n = *n_ptr;
-	const size_t cap = ws.capacity;
-	const DebugFlags F = debug_flags(U);
-	const uint32_t lane = threadIdx.x & 63u;
-	// [next, end) = unconsumed part of the list range this wave currently owns (wave-uniform).
-	// Ranges of SDFR_GRAB entries are claimed from a per-round cursor with one atomic each, so
-	// the load balances itself whatever the grid size and residency are.
-	uint32_t next = 0, end = 0;
-	bool exhausted = n == 0;
-
-	int state = LANE_IDLE;
-	uint32_t pid = 0;
-	March m = march_begin(V3s(0.f), V3s(0.f));
-	typename Scene::RayInv R = {};
-	float inside_sign = 1.f, max_range = 0.f, baseline = 0.f, g0 = 0.f, g1 = 0.f;
-	uint32_t evals = 0;       // of the current ray
-	uint32_t tot_evals = 0, tot_hits = 0;
-
-	for (;;)
-	{
-		const unsigned long long idle = __ballot(state == LANE_IDLE);
-		if (idle)
-		{
-			if (next == end && !exhausted)
-			{
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(cursor, (uint32_t)SDFR_GRAB);
-				base = __builtin_amdgcn_readfirstlane(base);
-				if (base >= n)
-					exhausted = true;
-				else
-				{
-					next = base;
-					end = base + SDFR_GRAB < n ? base + SDFR_GRAB : n;
-				}
-			}
-			const uint32_t n_idle = (uint32_t)__popcll(idle);
-			if (next == end)
-			{
-				if (n_idle == 64u) break; // list drained and every lane finished
-			}
-			else if (n_idle >= SDFR_REFILL_THRESHOLD || n_idle == 64u)
-			{
-				// hand the next list entries to the idle lanes, in lane order
-				const uint32_t avail = end - next;
-				if (state == LANE_IDLE)
-				{
-					const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-					if (rank < avail)
-					{
-						const uint32_t p = list[next + rank];
-						if (p != SDFR_INVALID_PIXEL)
-						{
-							pid = p;
-							const RayRec ray = load_ray(ws.ray_cur, cap, pid);
-							R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
-							inside_sign = ray_inside_sign(ray);
-							max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
-							m = march_begin(ray.pos, ray.dir);
-							evals = 0;
-							state = LANE_MARCH;
-						}
-					}
-				}
-				next += n_idle < avail ? n_idle : avail;
-			}
-		}
-
-		if (state != LANE_IDLE)
-		{
-			// one scene-distance evaluation per lane: a march sample or a normal sample
-			const bool marching = state == LANE_MARCH;
-			if (marching) march_pre(m);
-			const vec3 hp = march_pos(m);
-			vec3 p = hp;
-			if (state == LANE_GRAD0) p = grad_sample_pos(hp, 0, SDFR_GRAD_EPS);
-			if (state == LANE_GRAD1) p = grad_sample_pos(hp, 1, SDFR_GRAD_EPS);
-			if (state == LANE_GRAD2) p = grad_sample_pos(hp, 2, SDFR_GRAD_EPS);
-			const float dist = map_geometry<Scene, DBG>(U, F, R, p, m.dir, marching);
-
-			if (marching)
-			{
-				evals++;
-				const int status = march_advance(m, dist * inside_sign, max_range, (uint32_t)U.iter_count);
-				if (status == MARCH_HIT)
-				{
-					baseline = m.d * inside_sign;
-					state = LANE_GRAD0;
-				}
-				else if (status == MARCH_MISS)
-				{
-					ws.result[RS_STATUS * cap + pid] = __uint_as_float((uint32_t)MARCH_MISS << 24 | m.iter);
-					tot_evals += evals;
-					if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
-					state = LANE_IDLE;
-				}
-			}
-			else if (state == LANE_GRAD0)
-			{
-				g0 = dist - baseline;
-				state = LANE_GRAD1;
-			}
-			else if (state == LANE_GRAD1)
-			{
-				g1 = dist - baseline;
-				state = LANE_GRAD2;
-			}
-			else
-			{
-				const vec3 nrm = normalize(V3(g0, g1, dist - baseline));
-				ws.result[RS_STATUS * cap + pid] = __uint_as_float((uint32_t)MARCH_HIT << 24 | m.iter);
-				ws.result[RS_T * cap + pid] = m.t;
-				ws.result[RS_D * cap + pid] = m.d;
-				ws.result[RS_NX * cap + pid] = nrm.x;
-				ws.result[RS_NY * cap + pid] = nrm.y;
-				ws.result[RS_NZ * cap + pid] = nrm.z;
-				tot_evals += evals;
-				tot_hits += 1;
-				if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
-				state = LANE_IDLE;
-			}
-		}
-	}
-	block_add_totals(totals, 0, 0, tot_evals, tot_hits);
-}
-
-// ---- k_shade -----------------------------------------------------------------------------------------
-template <class Scene, bool DBG>
-__global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
-	const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ next_list, uint32_t *next_n, int round, void *out, int format,
-	uint32_t *pixel_stats, RenderTotals *totals)
-{
-	const uint32_t n = *n_ptr;
-	const size_t cap = ws.capacity;
-	const DebugFlags F = debug_flags(U);
-	__shared__ uint32_t s_count, s_base;
-	uint32_t n_rays = 0, n_done = 0;
-
-	for (uint32_t base = blockIdx.x * SDFR_BLOCK; base < n; base += gridDim.x * SDFR_BLOCK)
-	{
-		if (threadIdx.x == 0) s_count = 0;
-		__syncthreads();
-		const uint32_t i = base + threadIdx.x;
-		uint32_t pid = SDFR_INVALID_PIXEL;
-		if (i < n) pid = list[i];
-		bool alive = false;
-		if (pid != SDFR_INVALID_PIXEL)
-		{
-			n_rays++;
-			const RayRec ray = load_ray(ws.ray_cur, cap, pid);
-			int px, py;
-			pid_to_pixel(U, rm, pid, px, py);
-			const PixelRay pr = pixel_ray(U, px, py);
-			const uint32_t status_iter = __float_as_uint(ws.result[RS_STATUS * cap + pid]);
-			const uint32_t status = status_iter >> 24, iter = status_iter & 0xffffffu;
-
-			uint64_t depths = (uint64_t)ws.qdepth_lo[pid] | ((uint64_t)ws.qdepth_hi[pid] << 32);
-			int count = 0;
-			for (int s = 0; s < SDFR_MAX_RAYS; ++s)
-				count += (((depths >> (8 * s)) & 0xffu) != RAY_DEPTH_INVALID) ? 1 : 0;
-			float hdr = ws.accum[3 * cap + pid];
-
-			vec3 add;
-			GlobalRayStore store = {ws.ray_queue, cap, pid}; // the pixel's pending rays (48-byte records)
-			if (status == MARCH_HIT)
-			{
-				HitInfo hit;
-				hit.t = ws.result[RS_T * cap + pid];
-				hit.d = ws.result[RS_D * cap + pid];
-				hit.iter = iter;
-				hit.normal = V3(ws.result[RS_NX * cap + pid], ws.result[RS_NY * cap + pid], ws.result[RS_NZ * cap + pid]);
-				hit.pos = mad(ray.dir, hit.t, ray.pos);
-				const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
-				Spawner<GlobalRayStore> q(store, depths, count, U.ray_count);
-				add = shade_hit<Scene, DBG, GlobalRayStore>(U, F, ray, pr, hit, max_range, hdr, q);
-				depths = q.depths;
-				count = q.count;
-				if (pixel_stats) pixel_stats[3 * (size_t)pid + 2] += 1;
-			}
-			else
-			{
-				add = shade_miss<Scene>(U, ray, iter);
-			}
-			const vec3 acc = V3(ws.accum[0 * cap + pid], ws.accum[1 * cap + pid], ws.accum[2 * cap + pid]) + add;
-			if (pixel_stats) pixel_stats[3 * (size_t)pid + 0] += 1;
-
-			if (count > 0 && round + 1 < U.bounce_count)
-			{
-				// pop the pixel's next ray: it is traced in the next round
-				const int slot = queue_next(depths, U.ray_count);
-				const RayRec nr = store.get(slot);
-				store_ray(ws.ray_cur, cap, pid, nr);
-				depths = queue_set_depth(depths, slot, RAY_DEPTH_INVALID);
-				ws.qdepth_lo[pid] = (uint32_t)depths;
-				ws.qdepth_hi[pid] = (uint32_t)(depths >> 32);
-				ws.accum[0 * cap + pid] = acc.x;
-				ws.accum[1 * cap + pid] = acc.y;
-				ws.accum[2 * cap + pid] = acc.z;
-				ws.accum[3 * cap + pid] = hdr;
-				alive = true;
-			}
-			else
-			{
-				store_pixel(out, format, pid, V4(acc.x, acc.y, acc.z, abs1(hdr)), (uint32_t)rm.local_rows * (uint32_t)U.width);
-				n_done++;
-			}
-		}
-		// append the surviving pixels to the next round's list: one atomic per block
-		uint32_t my_off = 0;
-		if (alive) my_off = atomicAdd(&s_count, 1u);
-		__syncthreads();
-		if (threadIdx.x == 0 && s_count) s_base = atomicAdd(next_n, s_count);
-		__syncthreads();
-		if (alive) next_list[s_base + my_off] = pid;
-		__syncthreads();
-	}
-	block_add_totals(totals, n_done, n_rays, 0, 0);
+	hipLaunchKernelGGL(k_init, dim3((n_work + SDFR_BLOCK - 1) / SDFR_BLOCK), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, ws, pixel_stats);
+	return hipGetLastError();
 }
 
 // ---- strip assembly on the root (multi-GPU) ---------------------------------------------------------
@@ -482,87 +243,37 @@ int device_cu_count(int device)
 	return prop.multiProcessorCount;
 }
 
-template <class Scene, bool DBG>
-static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-	const WavefrontWorkspace &ws, hipStream_t stream)
-{
-	const uint32_t n_work = work_items(U, rm);
-	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
-	const uint32_t blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, totals,
-		ws.ray_queue, ws.capacity);
-	return launch_reduce_totals(ws.partials, blocks, totals, stream);
-}
+// the per-scene launchers live in SDFR_GROUPS translation units (sdfr_kernels_group.hip); scene i is in group i % SDFR_GROUPS
+#define SDFR_DECLARE_GROUP(G) \
+	hipError_t launch_pixel_group##G(int, const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t); \
+	hipError_t launch_wavefront_group##G(int, const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, \
+		hipEvent_t *, hipEvent_t *, int *);
+SDFR_FOR_EACH_GROUP(SDFR_DECLARE_GROUP)
+#undef SDFR_DECLARE_GROUP
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
 {
-	switch (scene)
+	if (scene < 0 || scene >= SDFR_SCENE_COUNT) return hipErrorInvalidValue;
+	switch (scene % SDFR_GROUPS)
 	{
-#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_pixel<S, true>(U, rows, out, format, pixel_stats, totals, ws, stream) : run_pixel<S, false>(U, rows, out, format, pixel_stats, totals, ws, stream);
-		SDFR_FOR_EACH_SCENE(SDFR_RUN)
-#undef SDFR_RUN
+#define SDFR_CALL_GROUP(G) case G: return launch_pixel_group##G(scene, U, rows, out, format, pixel_stats, totals, ws, stream);
+		SDFR_FOR_EACH_GROUP(SDFR_CALL_GROUP)
+#undef SDFR_CALL_GROUP
 	default: return hipErrorInvalidValue;
 	}
-}
-
-template <class Scene, bool DBG>
-static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-	const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events, int *n_rounds_out)
-{
-	const uint32_t n_work = work_items(U, rm);
-	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue; // lists are indexed by work item, state by pixel id < n_work
-	const uint32_t init_blocks = (n_work + SDFR_BLOCK - 1) / SDFR_BLOCK;
-	hipLaunchKernelGGL(k_init, dim3(init_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, n_work, ws, pixel_stats);
-
-	int device = 0;
-	(void)hipGetDevice(&device);
-	const int cus = device_cu_count(device);
-	int march_blocks_per_cu = 0, shade_blocks_per_cu = 0;
-	(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&march_blocks_per_cu, k_march<Scene, DBG>, SDFR_BLOCK, 0);
-	(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_blocks_per_cu, k_shade<Scene, DBG>, SDFR_BLOCK, 0);
-	if (march_blocks_per_cu < 1) march_blocks_per_cu = 1;
-	if (shade_blocks_per_cu < 1) shade_blocks_per_cu = 1;
-	// persistent grids: what the occupancy query calls resident (it may over-state by a block
-	// per CU for SGPR-heavy kernels; harmless here because work is claimed dynamically), but
-	// never more waves than there are ranges to claim
-	const uint32_t grabs = (n_work + SDFR_GRAB - 1u) / SDFR_GRAB;
-	uint32_t march_blocks = (uint32_t)(cus * march_blocks_per_cu);
-	if (march_blocks > (grabs + 3u) / 4u) march_blocks = (grabs + 3u) / 4u;
-	if (march_blocks < 1) march_blocks = 1;
-	uint32_t shade_blocks = (uint32_t)(cus * shade_blocks_per_cu);
-	if (shade_blocks > init_blocks) shade_blocks = init_blocks;
-	if (shade_blocks < 1) shade_blocks = 1;
-
-	uint32_t *list_cur = ws.list_a, *list_next = ws.list_b;
-	const int rounds = U.bounce_count;
-	for (int r = 0; r < rounds; ++r)
-	{
-		if (march_events) (void)hipEventRecord(march_events[2 * r], stream);
-		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, ws, list_cur, ws.counters + r,
-			ws.counters + 32 + r, pixel_stats, totals);
-		if (march_events) (void)hipEventRecord(march_events[2 * r + 1], stream);
-		if (shade_events) (void)hipEventRecord(shade_events[2 * r], stream);
-		hipLaunchKernelGGL((k_shade<Scene, DBG>), dim3(shade_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, ws, list_cur, ws.counters + r, list_next,
-			ws.counters + r + 1, r, out, format, pixel_stats, totals);
-		if (shade_events) (void)hipEventRecord(shade_events[2 * r + 1], stream);
-		uint32_t *t = list_cur;
-		list_cur = list_next;
-		list_next = t;
-	}
-	if (n_rounds_out) *n_rounds_out = rounds;
-	return hipGetLastError();
 }
 
 hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
 	int *n_rounds_out)
 {
-	switch (scene)
+	if (scene < 0 || scene >= SDFR_SCENE_COUNT) return hipErrorInvalidValue;
+	switch (scene % SDFR_GROUPS)
 	{
-#define SDFR_RUN(I, S) case I: return frame_needs_debug(U) ? run_wavefront<S, true>(U, rows, out, format, pixel_stats, totals, ws, stream, march_events, shade_events, n_rounds_out) : run_wavefront<S, false>(U, rows, out, format, pixel_stats, totals, ws, stream, march_events, shade_events, n_rounds_out);
-		SDFR_FOR_EACH_SCENE(SDFR_RUN)
-#undef SDFR_RUN
+#define SDFR_CALL_GROUP(G) case G: return launch_wavefront_group##G(scene, U, rows, out, format, pixel_stats, totals, ws, stream, march_events, shade_events, n_rounds_out);
+		SDFR_FOR_EACH_GROUP(SDFR_CALL_GROUP)
+#undef SDFR_CALL_GROUP
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -104,9 +104,14 @@ SDF_HD float rne1(float a) { return __builtin_rintf(a); }      // HLSL round(): 
 // it is NOT valid; every call site passes a sum of squares or a guarded discriminant of
 // scene-scale quantities, and the oracle's census build counts out-of-domain arguments over
 // the test and bench workloads (zero).  NaN propagates.
+//
+// SDFR_SAFE_MATH (what scenes compiled at run time get unless their text asks for the fast forms,
+// sdfr_jit.cpp): sqrt1 / rcp1 / div_c are the plain IEEE operations, valid for every input.  The
+// built-in scenes are covered by the domain census and the fuzz runs; a user's scene text and
+// variable ranges are not, and outside the domains the fast forms silently differ from IEEE.
 SDF_HD float sqrt1(float a)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDFR_SAFE_MATH)
 	const float y = __builtin_amdgcn_rsqf(a + 0x1p-126f);
 	const float g = a * y;
 	const float h = 0.5f * y;
@@ -123,7 +128,7 @@ SDF_HD float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
 // for a = +-0, +-inf and EVERY 2^-100 <= |a| <= 2^100 (sdfr_selftest_math what = 4).
 SDF_HD float rcp1(float a)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDFR_SAFE_MATH)
 	const float y = __builtin_amdgcn_rcpf(a);
 	const float r = __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
 	return __builtin_amdgcn_class(a, 0x260 | 0x204) ? y : r; // +-0 (0x60) and +-inf (0x204): rcp is exact there
@@ -141,7 +146,7 @@ SDF_HD float rsqrt1(float a) { return rcp1(sqrt1(a)); }
 // (sdfr_selftest_math) over a = +-0 and 2^-100 <= |a| <= 2^110.  Only for verified constants.
 SDF_HD float div_c(float a, float c, float rc)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDFR_SAFE_MATH)
 	const float q = a * rc;
 	return __builtin_fmaf(-__builtin_fmaf(c, q, -a), rc, q);
 #else

@@ -277,6 +277,9 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	// the fold kernel that follows adds into the totals: clear them here (kernel boundary = ordering)
 	if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = 0ull;
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
+#ifdef SDFR_WAVE_TRACE
+	const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+#endif
 	const uint32_t w = blockIdx.x * SDFR_PIXEL_BLOCK + threadIdx.x;
 	PixelCounters c = {};
 	uint32_t npix = 0;
@@ -295,6 +298,23 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		}
 		npix = 1;
 	}
+#ifdef SDFR_WAVE_TRACE
+	// developer build (tools/wave_trace.py): the per-block record carries when and where the wave ran
+	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, march evaluations
+	{
+		uint32_t ev = c.march_evals;
+		for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+		if (threadIdx.x == 0)
+		{
+			unsigned long long *rec = reinterpret_cast<unsigned long long *>(&partials[blockIdx.x]);
+			rec[0] = trace_t0;
+			rec[1] = __builtin_amdgcn_s_memrealtime();
+			rec[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+			rec[3] = ev;
+		}
+		return;
+	}
+#endif
 #ifdef SDFR_PHASE_CLOCKS
 	// the totals carry wave clocks instead of counts: pixels <- whole pixel loop, rays <- march,
 	// march_evals <- shading of escaped rays (background), hits <- normals + shading of hits; per wave the lane that stayed longest speaks

@@ -7,8 +7,8 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 SCENES_DIR = os.path.join(os.path.dirname(CSRC), "scenes")
 
 
-def aot_scene_source(struct_name):
-    for fn in ("sdfr_scenes.h", "sdfr_scenes2.h", "sdfr_scenes3.h", "sdfr_scenes4.h"):
+def aot_scene_source(struct_name, files=("sdfr_scenes.h", "sdfr_scenes2.h", "sdfr_scenes3.h", "sdfr_scenes4.h")):
+    for fn in files:
         text = open(os.path.join(CSRC, fn)).read()
         m = re.search(r"^struct %s\n\{\n.*?^\};\n" % struct_name, text, re.S | re.M)
         if m:

@@ -22,16 +22,24 @@ def renderer():
     r.close()
 
 
-@pytest.mark.parametrize("scene,struct_name,variables", [
-    ("fast_sphere", "SceneFastSphere", None),
-    ("labyrinth", "SceneLabyrinth", None),
-    ("lense", "SceneLense", dict(mixing=0.8, zpos=9.0)),
-    ("light_shadows", "SceneLightShadows", None),
+# run-time scenes get the plain IEEE sqrt / reciprocal / constant division unless their text opts into the
+# exact fast forms (token SDFR_FAST_EXACT_MATH, sdfr_jit.cpp): on the verified domains -- where the built-in
+# scenes stay -- both give the same bits, so both must match the oracle
+@pytest.mark.parametrize("scene,struct_name,variables,fast_math", [
+    ("fast_sphere", "SceneFastSphere", None, False),
+    ("labyrinth", "SceneLabyrinth", None, False),
+    ("labyrinth", "SceneLabyrinth", None, True),
+    ("lense", "SceneLense", dict(mixing=0.8, zpos=9.0), True),
+    ("light_shadows", "SceneLightShadows", None, False),
 ])
-def test_built_in_scene_compiled_at_run_time_matches_oracle(renderer, oracle, scene, struct_name, variables):
+def test_built_in_scene_compiled_at_run_time_matches_oracle(renderer, oracle, scene, struct_name, variables, fast_math):
     f = _setup(renderer, oracle, scene, 0.75, variables=variables)
     table_aot = [(v.name, v.minval, v.maxval, v.start, v.step) for v in renderer.getVariableMap().values()]
-    renderer.initShaderSource(scene + "_rt", aot_scene_source(struct_name))
+
+    def scene_text(name):
+        return ("// SDFR_FAST_EXACT_MATH: domains checked by the oracle census\n" if fast_math else "") + aot_scene_source(name)
+
+    renderer.initShaderSource(scene + "_rt", scene_text(struct_name))
     assert renderer.currentScene() == scene + "_rt"
     # same variable table as the built-in scene (same tags in the text), then same values
     assert [(v.name, v.minval, v.maxval, v.start, v.step) for v in renderer.getVariableMap().values()] == table_aot
@@ -40,7 +48,7 @@ def test_built_in_scene_compiled_at_run_time_matches_oracle(renderer, oracle, sc
     assert _compare(renderer, oracle, scene, f, 1), "within tolerance but not bit-identical"
     # the debug-plane specialisation of the run-time kernel
     f2 = _setup(renderer, oracle, scene, 0.75, variables=dict(debug_ny=1.0, debug_y=0.5, **(variables or {})))
-    renderer.initShaderSource(scene + "_rt", aot_scene_source(struct_name))
+    renderer.initShaderSource(scene + "_rt", scene_text(struct_name))
     for k, v in dict(debug_ny=1.0, debug_y=0.5, **(variables or {})).items():
         assert renderer.setValue(k, v)
     assert _compare(renderer, oracle, scene, f2, 1)
