@@ -50,6 +50,7 @@ static void free_workspace(sdfr_renderer *r)
 	(void)hipFree(w.list_b);
 	(void)hipFree(w.counters);
 	(void)hipFree(w.partials);
+	(void)hipFree(w.tile_cursors);
 	w = WavefrontWorkspace{};
 	r->wavefront_capacity = 0;
 }
@@ -71,6 +72,11 @@ static int ensure_workspace(sdfr_renderer *r, size_t pixels, bool wavefront)
 		};
 		alloc((void **)&w.ray_queue, sizeof(float) * 12 * SDFR_MAX_RAYS * n); // 48-byte records (pixel schedule) / 11 field arrays (wavefront)
 		alloc((void **)&w.partials, sizeof(RenderTotals) * (n / 64 + 1));
+		if (e == hipSuccess && w.tile_cursors == nullptr)
+		{
+			alloc((void **)&w.tile_cursors, sizeof(uint32_t) * (size_t)pixel_tile_cursor_words());
+			if (e == hipSuccess) e = hipMemset(w.tile_cursors, 0, sizeof(uint32_t) * (size_t)pixel_tile_cursor_words());
+		}
 		if (wavefront)
 		{
 			alloc((void **)&w.ray_cur, sizeof(float) * 11 * n);
@@ -111,6 +117,8 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 		int v = atoi(t);
 		if (v >= 3 && v <= 6) r->tile_w_log2 = v;
 	}
+	if (const char *t = getenv("SDFR_TILE_ORDER")) // developer knob: 0 top to bottom, 1 bottom to top, 2 interleaved rows
+		r->tile_order = atoi(t);
 	frame_defaults(r->U);
 	// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
 	host::Camera cam;
@@ -501,6 +509,8 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	rm.priv_count = mode == RENDER_FULL ? 0 : r->priv_count;
 	rm.priv_period = mode == RENDER_FULL ? 1 : r->priv_period;
 	rm.direct = mode == RENDER_PRIVATE ? 1 : 0;
+	rm.tile_row_mul = 1u;
+	rm.tile_row_add = 0u;
 	const uint32_t frame_strips = (uint32_t)((height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS);
 	if (mode == RENDER_FULL)
 		rm.local_rows = height;
@@ -547,6 +557,22 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 		if (last_row_end > height && out_bytes) SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
 	}
 
+	{
+		// the order the launch's waves take the tile rows in (developer knob SDFR_TILE_ORDER; RowMap)
+		const uint32_t th = 64u >> rm.tile_w_log2, tile_rows = ((uint32_t)rm.local_rows + th - 1u) / th;
+		if (r->tile_order == 1 && tile_rows > 1) // bottom to top
+		{
+			rm.tile_row_mul = tile_rows - 1u;
+			rm.tile_row_add = tile_rows - 1u;
+		}
+		else if (r->tile_order == 2 && tile_rows > 2) // interleaved: successive hand-outs are ~0.62 of the image height apart
+		{
+			uint32_t m = (uint32_t)(0.6180339887 * tile_rows);
+			auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+			while (m > 1 && gcd(m, tile_rows) != 1) --m;
+			rm.tile_row_mul = m < 1 ? 1u : m;
+		}
+	}
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;
@@ -656,7 +682,9 @@ int sdfr_debug_read_partials(sdfr_renderer *r, void *host, size_t records)
 {
 	if (!r || !host) return SDFR_ERR_INVALID_ARGUMENT;
 	SDFR_HIP(hipStreamSynchronize(r->stream));
+	if (records > r->ws.capacity / 64 + 1) records = r->ws.capacity / 64 + 1;
 	SDFR_HIP(hipMemcpy(host, r->ws.partials, records * sizeof(RenderTotals), hipMemcpyDeviceToHost));
+	SDFR_HIP(hipMemset(r->ws.partials, 0, records * sizeof(RenderTotals))); // records the next launch does not write read as empty
 	return SDFR_OK;
 }
 #endif

@@ -108,6 +108,9 @@ struct RowMap
 	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
 	int priv_count, priv_period; // 0 <= priv_count < priv_period
 	int direct;                  // 1: this launch renders the private strips, pixel index = position in the full image
+	// order in which the launch's waves take the tile rows: tile row (ty * tile_row_mul + tile_row_add) % tile_rows
+	// is the ty-th to be handed out (an affine permutation: mul coprime to tile_rows; 1, 0 = top to bottom)
+	uint32_t tile_row_mul, tile_row_add;
 };
 
 // local strip index of this launch -> strip index in the frame

@@ -90,11 +90,11 @@ std::string jit_translation_unit(const std::string &scene_source, const std::vec
 	tu += "\n#line 1 \"sdfr_jit_kernels\"\n";
 	tu += "extern \"C\" __global__ void sdfr_jit_prepare(FrameU *U) { if (blockIdx.x == 0 && threadIdx.x == 0) Scene::prepare(*U); }\n";
 	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)\n"
-		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap); }\n";
+		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
+		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
 	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)\n"
-		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap); }\n";
+		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
+		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
 	tu += "} // namespace sdfr\n";
 	return tu;
 }
@@ -199,16 +199,23 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	uint32_t n_work = launch_work_items(U.width, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
 	const uint32_t bt = (uint32_t)pixel_block_threads();
-	const uint32_t blocks = (n_work + bt - 1u) / bt;
+	// a persistent launch, as for the scenes compiled ahead of time (run_pixel, sdfr_kernels_group.hip)
+	hipFunction_t fn = frame_needs_debug(U) ? js.pixel_debug : js.pixel;
+	int per_cu = 0, device = 0;
+	if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)bt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+	(void)hipGetDevice(&device);
+	uint32_t blocks = (uint32_t)(device_cu_count(device) * per_cu);
+	if (blocks > (n_work + bt - 1u) / bt) blocks = (n_work + bt - 1u) / bt;
 	FrameU frame = U;
 	RowMap rows = rm;
 	float *queue = ws.ray_queue;
 	size_t cap = ws.capacity;
 	RenderTotals *partials = ws.partials;
-	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap};
-	const hipError_t e = hipModuleLaunchKernel(frame_needs_debug(U) ? js.pixel_debug : js.pixel, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
+	uint32_t *cursors = ws.tile_cursors;
+	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap, &cursors};
+	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
-	return launch_reduce_totals(partials, blocks, totals, stream);
+	return launch_reduce_totals(partials, blocks, totals, stream, cursors);
 }
 
 } // namespace sdfr

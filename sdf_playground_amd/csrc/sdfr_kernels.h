@@ -21,7 +21,8 @@ struct WavefrontWorkspace
 	uint32_t *list_a;    // [capacity] pixels with a ray in flight (ping)
 	uint32_t *list_b;    // [capacity] (pong)
 	uint32_t *counters;  // [64] list sizes per round and misc
-	RenderTotals *partials; // [capacity / 256 + 1] per-block counter sums of the pixel schedule
+	RenderTotals *partials; // [capacity / 64 + 1] per-block counter sums of the pixel schedule
+	uint32_t *tile_cursors; // [8 x 32] tile hand-out counters of the pixel kernel (TileQueue), zero between launches
 };
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
@@ -43,7 +44,10 @@ hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatc
 // wavefront schedule, scene-independent start of a frame: primary rays, empty queues, round-0 list
 hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_work, const WavefrontWorkspace &ws, uint32_t *pixel_stats, hipStream_t stream);
 
-hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream);
+// folds the per-block partial sums of a pixel-schedule launch into `totals` and puts the tile cursors back to zero
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors);
+// resident blocks of the device for a kernel whose occupancy query says `blocks_per_cu`
+int pixel_tile_cursor_words();
 
 int pixel_block_threads(); // block size of the pixel kernels (partials are sized by it)
 int device_cu_count(int device);

@@ -46,8 +46,11 @@ uint32_t launch_work_items(int width, const RowMap &rm)
 // several independent loads in flight per thread, then ONE set of four atomics per block.
 #define SDFR_REDUCE_THREADS 256
 #define SDFR_REDUCE_BLOCKS 64
-__global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals)
+__global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals,
+	uint32_t *tile_cursors)
 {
+	// the pixel kernel before this one has drained its tile cursors: back to zero for the next launch
+	if (blockIdx.x == 0 && threadIdx.x < SDFR_TILE_CURSORS) tile_cursors[threadIdx.x * SDFR_TILE_CURSOR_STRIDE] = 0u;
 	__shared__ unsigned long long acc[4];
 	if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
 	__syncthreads();
@@ -79,12 +82,14 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 	__syncthreads();
 	if (threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(totals) + threadIdx.x, acc[threadIdx.x]);
 }
-hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream)
+int pixel_tile_cursor_words() { return SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE; }
+
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors)
 {
 	uint32_t blocks = (n_blocks + SDFR_REDUCE_THREADS * 4 - 1) / (SDFR_REDUCE_THREADS * 4);
 	if (blocks > SDFR_REDUCE_BLOCKS) blocks = SDFR_REDUCE_BLOCKS;
 	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals);
+	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals, tile_cursors);
 	return hipGetLastError();
 }
 

@@ -25,9 +25,9 @@ static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_wo
 // =================================================================================================
 template <class Scene, bool DBG>
 __global__ SDFR_PIXEL_KERNEL_ATTRS void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)
+	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)
 {
-	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap);
+	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors);
 }
 
 // =================================================================================================
@@ -274,10 +274,24 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 {
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
-	const uint32_t blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
+	// a persistent launch: as many blocks as stay resident, each pulling tiles until none is left
+	// (TileQueue, sdfr_pixel_kernel.h).  The occupancy query may over-state by a block per CU for
+	// SGPR-heavy kernels (MI355X_MICROARCH.md); a surplus block simply starts when another has ended.
+	static int blocks_per_cu = 0; // per instantiation
+	if (blocks_per_cu == 0)
+	{
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_pixel<Scene, DBG>, SDFR_PIXEL_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+		blocks_per_cu = n;
+	}
+	int device = 0;
+	(void)hipGetDevice(&device);
+	const uint32_t tiles_blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
+	uint32_t blocks = (uint32_t)(device_cu_count(device) * blocks_per_cu);
+	if (blocks > tiles_blocks) blocks = tiles_blocks;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, totals,
-		ws.ray_queue, ws.capacity);
-	return launch_reduce_totals(ws.partials, blocks, totals, stream);
+		ws.ray_queue, ws.capacity, ws.tile_cursors);
+	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors);
 }
 
 template <class Scene, bool DBG>

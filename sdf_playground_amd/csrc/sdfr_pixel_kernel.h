@@ -47,7 +47,13 @@ __device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm,
 	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << tw_log2) - 1u) >> tw_log2;
 	const uint32_t tile = w >> 6, lane = w & 63u;
-	const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+	const uint32_t tx = tile % tiles_x;
+	uint32_t ty = tile / tiles_x;
+	if (rm.tile_row_mul != 1u || rm.tile_row_add != 0u) // the order the tile rows are handed out in (RowMap)
+	{
+		const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
+		ty = (ty * rm.tile_row_mul + rm.tile_row_add) % tiles_y;
+	}
 	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
 	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
@@ -268,41 +274,110 @@ struct LdsCachedRayStore
 	}
 };
 
+// ---- tile hand-out of the persistent pixel kernel ---------------------------------------------------
+// The launch holds exactly as many waves as the chip keeps resident; a wave renders 8x8 tiles until none
+// is left.  Why not one workgroup per tile: the hardware deals workgroups to the 32 shader engines in
+// strict rotation (block n -> XCD n % 8, engine (n / 8) % 4: tools/wave_trace.py shows exactly 1/32 of
+// the blocks on each), so an engine that happens to draw long-running tiles holds up the hand-out while
+// the others run dry -- 15-25 % of the wave slots stood empty through the middle of a labyrinth frame
+// (slot refill gap 9 us mean against 0.8 us while all tiles are alike).  Pulling tiles from a counter
+// has no such coupling.
+//   * the first tile of wave v is tile v: no atomic at start-up (7168 waves on one word would take ~80 us);
+//   * the other tiles are handed out through 8 cursors, 128 bytes apart (one word sustains ~88
+//     hand-outs per us, a 4K frame needs ~100): dynamic tile j belongs to cursor j % 8, a wave pulls
+//     from the cursor of its XCD and moves on to the next cursor once one has run out.  Which cursor a
+//     wave starts with is a matter of speed only: any wave may pull from any cursor.
+//   * k_reduce_totals, which follows every launch, puts the cursors back to zero.
+#define SDFR_TILE_CURSORS 8
+#define SDFR_TILE_CURSOR_STRIDE 32 // uint32 words between two cursors
+#define SDFR_NO_TILE 0xffffffffu
+struct TileQueue
+{
+	uint32_t *cursors;
+	uint32_t n_tiles, n_waves; // tiles of the launch; waves of the launch (tiles [0, n_waves) are the waves' first tiles)
+	uint32_t shard, dead;      // cursor this wave pulls from; bit s: cursor s has run out
+	__device__ __forceinline__ uint32_t first(uint32_t wave)
+	{
+		dead = 0;
+		shard = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (SDFR_TILE_CURSORS - 1); // HW_REG_XCC_ID
+		return wave < n_tiles ? wave : SDFR_NO_TILE;
+	}
+	// wave-uniform; one atomic by one lane per tile
+	__device__ __forceinline__ uint32_t next()
+	{
+		if (n_tiles <= n_waves) return SDFR_NO_TILE;
+		const uint32_t dynamic = n_tiles - n_waves;
+		while (dead != (1u << SDFR_TILE_CURSORS) - 1u)
+		{
+			const uint32_t in_shard = shard < dynamic ? (dynamic - shard + SDFR_TILE_CURSORS - 1u) / SDFR_TILE_CURSORS : 0u;
+			uint32_t k = 0;
+			if ((threadIdx.x & 63u) == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, 1u) : 0u;
+			k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+			if (k < in_shard) return n_waves + shard + SDFR_TILE_CURSORS * k;
+			dead |= 1u << shard;
+			shard = (shard + 1u) & (SDFR_TILE_CURSORS - 1u);
+		}
+		return SDFR_NO_TILE;
+	}
+};
+
 // body of the pixel kernel; the __global__ wrappers are k_pixel (scenes compiled ahead of time,
-// sdfr_kernels.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
+// sdfr_kernels_group.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
 template <class Scene, bool DBG>
 __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap)
+	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)
 {
 	// the fold kernel that follows adds into the totals: clear them here (kernel boundary = ordering)
 	if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = 0ull;
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
+	// the lane's running counters over its tiles (pixels, rays, march evaluations, hits) live in LDS as well:
+	// they are touched once per pixel, and as registers they would be live across the whole bounce loop
+	__shared__ uint32_t lds_counts[4][SDFR_PIXEL_BLOCK];
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	lds_u32 *counts = (lds_u32 *)&lds_counts[0][threadIdx.x];
+	counts[0 * SDFR_PIXEL_BLOCK] = 0u; counts[1 * SDFR_PIXEL_BLOCK] = 0u; counts[2 * SDFR_PIXEL_BLOCK] = 0u; counts[3 * SDFR_PIXEL_BLOCK] = 0u;
 #ifdef SDFR_WAVE_TRACE
 	const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+	uint32_t trace_tiles = 0;
 #endif
-	const uint32_t w = blockIdx.x * SDFR_PIXEL_BLOCK + threadIdx.x;
-	PixelCounters c = {};
-	uint32_t npix = 0;
-	PixelCoord pc;
-	if (w < n_work && work_to_pixel(U, rm, w, pc))
+	const uint32_t waves_per_block = SDFR_PIXEL_BLOCK / 64u;
+	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u};
+#ifdef SDFR_PHASE_CLOCKS
+	PixelCounters clk = {};
+#endif
+	for (uint32_t tile = tiles.first(blockIdx.x * waves_per_block + (threadIdx.x >> 6)); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
-		GlobalRayStore backing = {ray_queue, cap, pc.pid};
-		LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
-		vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, c, store);
-		store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
-		if (pixel_stats)
+		PixelCoord pc;
+		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc))
 		{
-			pixel_stats[3 * (size_t)pc.pid + 0] = c.rays;
-			pixel_stats[3 * (size_t)pc.pid + 1] = c.march_evals;
-			pixel_stats[3 * (size_t)pc.pid + 2] = c.hits;
+			PixelCounters pcnt = {};
+			GlobalRayStore backing = {ray_queue, cap, pc.pid};
+			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
+			vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, pcnt, store);
+			store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
+			if (pixel_stats)
+			{
+				pixel_stats[3 * (size_t)pc.pid + 0] = pcnt.rays;
+				pixel_stats[3 * (size_t)pc.pid + 1] = pcnt.march_evals;
+				pixel_stats[3 * (size_t)pc.pid + 2] = pcnt.hits;
+			}
+			counts[0 * SDFR_PIXEL_BLOCK] += 1u;
+			counts[1 * SDFR_PIXEL_BLOCK] += pcnt.rays;
+			counts[2 * SDFR_PIXEL_BLOCK] += pcnt.march_evals;
+			counts[3 * SDFR_PIXEL_BLOCK] += pcnt.hits;
+#ifdef SDFR_PHASE_CLOCKS
+			clk.clk_march += pcnt.clk_march; clk.clk_grad += pcnt.clk_grad; clk.clk_shade += pcnt.clk_shade; clk.clk_miss += pcnt.clk_miss; clk.clk_total += pcnt.clk_total;
+#endif
 		}
-		npix = 1;
+#ifdef SDFR_WAVE_TRACE
+		trace_tiles++;
+#endif
 	}
 #ifdef SDFR_WAVE_TRACE
 	// developer build (tools/wave_trace.py): the per-block record carries when and where the wave ran
-	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, march evaluations
+	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, tiles | march evaluations << 32
 	{
-		uint32_t ev = c.march_evals;
+		uint32_t ev = counts[2 * SDFR_PIXEL_BLOCK];
 		for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
 		if (threadIdx.x == 0)
 		{
@@ -310,12 +385,13 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 			rec[0] = trace_t0;
 			rec[1] = __builtin_amdgcn_s_memrealtime();
 			rec[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-			rec[3] = ev;
+			rec[3] = (unsigned long long)trace_tiles | ((unsigned long long)ev << 32);
 		}
 		return;
 	}
 #endif
 #ifdef SDFR_PHASE_CLOCKS
+	const PixelCounters &c = clk;
 	// the totals carry wave clocks instead of counts: pixels <- whole pixel loop, rays <- march,
 	// march_evals <- shading of escaped rays (background), hits <- normals + shading of hits; per wave the lane that stayed longest speaks
 	{
@@ -328,7 +404,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		return;
 	}
 #endif
-	block_store_totals(partials, npix, c.rays, c.march_evals, c.hits);
+	block_store_totals(partials, counts[0 * SDFR_PIXEL_BLOCK], counts[1 * SDFR_PIXEL_BLOCK], counts[2 * SDFR_PIXEL_BLOCK], counts[3 * SDFR_PIXEL_BLOCK]);
 }
 
 } // namespace sdfr

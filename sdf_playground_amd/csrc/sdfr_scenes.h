@@ -84,32 +84,57 @@ struct SceneCubeSea
 		return num / den;
 	}
 	struct Cell { vec3 cell_pos; float cube; bool is_other; };
+	static SDF_HD vec3 cell_position(vec3 p)
+	{
+		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(2.f, 2.f)); // x / 2 is an exact multiply already
+		return V3(rep.x, p.y, rep.y);
+	}
 	static SDF_HD Cell eval_cell(const FrameU &U, vec3 p)
 	{
 		Cell c;
-		vec2 rep = op_rep_inf(V2(p.x, p.z), V2(2.f, 2.f)); // x / 2 is an exact multiply already
-		c.cell_pos = V3(rep.x, p.y, rep.y);
+		c.cell_pos = cell_position(p);
+		const vec2 rep = V2(c.cell_pos.x, c.cell_pos.z);
 		vec2 cell_index = (V2(p.x, p.z) - rep) / 2.f;
 		vec2 q = cell_index * 0.5f + 0.25f;
 		vec2 sometimes = V2(rne1(frac1(q.x)), rne1(frac1(q.y)));
 		c.is_other = sometimes.x < 0.5f && sometimes.y < 0.5f;
 		float phase = cell_index.x + cell_index.y * 0.3f + U.stime;
 		vec2 sc = sincos1(phase);
-		vec2 r = op_rotate(rep, sc.y * 0.4f);
+		// the cube's rotation angle is cos(phase) * 0.4, at most 0.4 in magnitude: the reduction-free sincos
+		vec2 rsc = sincos1_small(sc.y * 0.4f);
+		vec2 r = rot2(rep, rsc.x, rsc.y);
 		vec3 cube_pos = V3(r.x, p.y, r.y);
 		float hs = c.is_other ? 0.25f : 0.5f;
 		c.cube = sd_box(cube_pos - V3(0.f, 2.f + sc.x, 0.f), V3s(hs)) - 0.15f;
 		return c;
 	}
+	// Every cube lies in the slab 0.35 <= y <= 3.65: its centre bobs at y = 2 + sin(phase), the box has a
+	// half height of at most 0.5 and is rounded by 0.15, and the rotation is about the vertical.  sd_box is
+	// at least its distance along one axis, so  cube >= max(p.y - 3.65, 0.35 - p.y).  The scene distance
+	// is a min() over floor, cube and cell guard: where that bound (with 0.01 of slack for rounding; the
+	// quantities are O(100) at most below y = 1024, above it the cube is evaluated as ever) is not below
+	// the smaller of floor and guard, the cube -- two sincos, a rotation and a box: 60 % of an evaluation
+	// -- cannot lower the minimum and is left out.  That is every step of a ray that travels above the
+	// cubes (sky-bound primary and reflection rays, which need the most steps: the guard stops them at
+	// every cell wall up to the range of 100) and the first steps of a shadow ray leaving the floor.
+	// Checked numerically in tests/test_scene_bounds_cpu.py.
+	static SDF_HD float cube_lower_bound(vec3 p, bool *valid)
+	{
+		*valid = p.y < 1024.f;
+		return max1(p.y - 3.66f, 0.34f - p.y);
+	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		Cell c = eval_cell(U, p);
-		d = min1(d, c.cube);
-		const vec2 num = R.barrier - V2(c.cell_pos.x, c.cell_pos.z);
+		const vec3 cell_pos = cell_position(p);
+		const vec2 num = R.barrier - V2(cell_pos.x, cell_pos.z);
 		const float tx = guard_quotient(num.x, dir.x, R.rdir.x, R.exact_x);
 		const float tz = guard_quotient(num.y, dir.z, R.rdir.y, R.exact_z);
-		return min1(d, min1(tx, tz));
+		// min() is taken over the same three values as map() does (floor, cube, guard): any order gives the same bits
+		const float d = min1(min1(3e38f, ground_dist(p, fast, R.ground)), min1(tx, tz));
+		bool valid;
+		const float lb = cube_lower_bound(p, &valid);
+		if (valid && lb >= d) return d;
+		return min1(d, eval_cell(U, p).cube);
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
@@ -405,19 +430,20 @@ struct SceneLense
 	// axis; sd_box is an exact distance, so both are >= |p - c| - 2.38 and can be left out of the
 	// min() whenever that bound is not below the running minimum (0.01 of slack for rounding;
 	// checked numerically in tests/test_scene_bounds_cpu.py).
+	//
+	// The two blob fields are slabs about y = -5 and y = +5: a blob is lerp(sphere r 1, box 1, 0.65) - 0.1
+	// of a point whose height above the field's plane is h, and both the sphere's and the box's distance
+	// are >= |h| - 1, so is their blend (weights 0.35 / 0.65), hence  blob >= |h| - 1.1.  Lens, light ball
+	// and pane live between the fields: close to them (nearer than ~3.9 minus the height) the repetition,
+	// sphere and box of both fields (100 of the ~200 instructions) cannot lower the minimum and are left
+	// out.  0.01 of slack; only below |y| = 1024, where the quantities are O(1000) at most.
+	static SDF_HD float blob_field_lower_bound(float h) { return abs1(h) - 1.11f; }
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool)
 	{
-		vec3 b1 = p - V3(0.f, -5.f, 0.f);
-		vec2 r1 = op_rep_inf_c(V2(b1.x, b1.z), 3.f, 1.0f / 3.f);
-		float d = min1(3e38f, blob(V3(r1.x, b1.y, r1.y)));
-
-		vec3 b2 = p - V3(0.f, 5.f, 0.f);
-		vec2 r2 = op_rep_inf_c(V2(b2.x, b2.z), 10.f, 1.0f / 10.f);
-		d = min1(d, blob(V3(r2.x, b2.y, r2.y)));
-
+		// min() over the same objects as map(), any order gives the same bits: the cheap ones first
 		vec3 lp = abs(p);
 		lp.z = lp.z - 5.1f;
-		d = min1(d, max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f)));
+		float d = min1(3e38f, max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f)));
 		d = min1(d, sd_sphere(p - V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]), 2.f));
 
 		vec3 mp = p - V3(0.f, 0.f, -5.f);
@@ -428,6 +454,20 @@ struct SceneLense
 			mp = V3(mr.x, mp.y, mr.y);
 			d = min1(d, sd_box(mp, V3(1.f, 2.f, 0.1f)));
 			d = min1(d, sd_box(mp, V3(1.1f, 2.1f, 0.08f)));
+		}
+
+		const bool far_out = !(abs1(p.y) < 1024.f); // or NaN: no culling there
+		vec3 b1 = p - V3(0.f, -5.f, 0.f);
+		if (far_out || !(blob_field_lower_bound(b1.y) >= d))
+		{
+			vec2 r1 = op_rep_inf_c(V2(b1.x, b1.z), 3.f, 1.0f / 3.f);
+			d = min1(d, blob(V3(r1.x, b1.y, r1.y)));
+		}
+		vec3 b2 = p - V3(0.f, 5.f, 0.f);
+		if (far_out || !(blob_field_lower_bound(b2.y) >= d))
+		{
+			vec2 r2 = op_rep_inf_c(V2(b2.x, b2.z), 10.f, 1.0f / 10.f);
+			d = min1(d, blob(V3(r2.x, b2.y, r2.y)));
 		}
 		return d;
 	}

@@ -173,3 +173,90 @@ extern "C" long long hostsim_check_distortion_bounds(long long n, unsigned seed)
 	}
 	return bad;
 }
+
+// the cube_sea scene's slab bound of a cell's cube and the reduction-free sincos of its rotation angle
+// (sdfr_scenes.h, SceneCubeSea; sdfr_math.h, sincos1_small)
+extern "C" long long hostsim_check_cube_sea_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 31337ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	FrameU U;
+	frame_defaults(U);
+	for (long long i = 0; i < n; ++i)
+	{
+		U.stime = rnd() * 40.f;
+		// a third of the samples around the slab's faces, a third room-scale, a third far out (still below y = 1024)
+		const float sy = (i % 3 == 0) ? 0.5f : ((i % 3 == 1) ? 8.f : 1000.f);
+		const float yc = (i & 8) ? 3.65f : 0.35f;
+		const vec3 p = V3((rnd() * 2.f - 1.f) * 120.f, yc + (rnd() * 2.f - 1.f) * sy, (rnd() * 2.f - 1.f) * 120.f);
+		bool valid;
+		const float lb = SceneCubeSea::cube_lower_bound(p, &valid);
+		// the bound carries 0.01 of slack: the computed cube distance must not come within half of it
+		if (valid && SceneCubeSea::eval_cell(U, p).cube < lb + 0.005f) ++bad;
+		// sincos1_small against sincos1, bit for bit, on its whole domain
+		const float x = (i & 1) ? (rnd() * 1.5f - 0.75f) : bits_f32((uint32_t)(rnd() * (float)0x3f400000u) | ((i & 2) ? 0x80000000u : 0u));
+		const vec2 a = sincos1(x), b = sincos1_small(x);
+		if (f32_bits(a.x) != f32_bits(b.x) || f32_bits(a.y) != f32_bits(b.y)) ++bad;
+	}
+	for (float x : {0.f, -0.f, 0.75f, -0.75f, 0.4f, -0.4f, 0.40000004f, 1e-30f, -1e-40f})
+	{
+		const vec2 a = sincos1(x), b = sincos1_small(x);
+		if (f32_bits(a.x) != f32_bits(b.x) || f32_bits(a.y) != f32_bits(b.y)) ++bad;
+	}
+	return bad;
+}
+
+// the lense scene's slab bound of its two blob fields (sdfr_scenes.h, SceneLense::dist)
+extern "C" long long hostsim_check_lense_field_bounds(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 5151ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		// height above the field's plane: a third close to the blobs' tops, a third room-scale, a third far (|y| < 1024)
+		const float hs = (i % 3 == 0) ? 1.3f : ((i % 3 == 1) ? 12.f : 1000.f);
+		const float h = (rnd() * 2.f - 1.f) * hs;
+		const float cell = (i & 1) ? 3.f : 10.f;
+		const vec2 r = op_rep_inf_c(V2((rnd() * 2.f - 1.f) * 300.f, (rnd() * 2.f - 1.f) * 300.f), cell, 1.0f / cell);
+		// the bound carries 0.01 of slack: the computed blob must not come within half of it
+		if (SceneLense::blob(V3(r.x, h, r.y)) < SceneLense::blob_field_lower_bound(h) + 0.005f) ++bad;
+	}
+	return bad;
+}
+
+// the terrain scene's octave skip (sdfr_scenes3.h, SceneTerrain::fbm): base() stays below 0.8661, and an
+// octave computed with the stand-in equals the octave computed with base() wherever the skip applies
+extern "C" long long hostsim_check_terrain_octave_skip(long long n, unsigned seed)
+{
+	unsigned long long state = seed * 2654435761ull + 8080ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	for (long long i = 0; i < n; ++i)
+	{
+		const float span = (i & 1) ? 12.f : 4000.f;
+		const vec3 p = V3((rnd() * 2.f - 1.f) * span, (rnd() * 2.f - 1.f) * span, (rnd() * 2.f - 1.f) * span);
+		const float base = SceneTerrain::base(p);
+		if (!(base <= 0.8661f)) ++bad;
+		float s = 1.f;
+		for (int k = (int)(rnd() * 10.f); k > 0; --k) s = s * 0.5f;
+		// running distances around the threshold, well above it, and huge
+		const float d = (i % 3 == 0) ? s * (1.3f + rnd() * 0.2f) : ((i % 3 == 1) ? s * (1.3f + rnd() * 50.f) : 1.3f * s + rnd() * rnd() * 1e6f);
+		if (SceneTerrain::octave_needs_base(d, s)) { ++bad; continue; }
+		const float b = d - 0.1f * s;
+		const float with_base = op_smin(op_smax2(s * base, b, 0.3f * s), d, 0.3f * s);
+		const float with_stand_in = op_smin(op_smax2(b - 0.6f * s, b, 0.3f * s), d, 0.3f * s);
+		if (f32_bits(with_base) != f32_bits(with_stand_in)) ++bad;
+	}
+	return bad;
+}

@@ -83,3 +83,71 @@ def test_distortion_bound_holds_and_culling_is_invisible(oracle):
         img, st = hostsim.render("distortion", hostsim.frame_from_oracle(f))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
         assert np.array_equal(st, rst)
+
+
+def test_cube_sea_bound_holds_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_cube_sea_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_cube_sea_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_cube_sea_bounds(3000000, 9) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    # from above the cubes (the bench camera's height), looking up from between them, grazing their tops, from inside
+    # the slab, straight down and straight up (guard divisors near zero), and far above the field
+    views = [((3.0, 4.5, 0.0), (4.0, 4.05, 0.6)), ((0.9, 0.2, 0.9), (3.0, 3.0, 5.0)), ((0.0, 3.7, 0.0), (30.0, 3.6, 7.0)), ((1.0, 2.0, 1.0), (9.0, 2.2, 4.0)),
+             ((0.5, 9.0, 0.5), (0.5, 0.0, 0.5001)), ((0.3, 0.1, 0.2), (0.3, 50.0, 0.2001)), ((5.0, 900.0, 5.0), (40.0, 0.0, 30.0)), ((2.0, 1200.0, 2.0), (2.5, 0.0, 2.0))]
+    for eye, at in views:
+        for stime, limits in ((0.0, {}), (1.7, dict(iter_count=128, max_cost_default=6))):
+            f = oracle.default_frame("cube_sea", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=stime)
+            for k, v in limits.items():
+                setattr(f, k, v)
+            ref, rst, _ = oracle.render("cube_sea", f, stats=True)
+            img, st = hostsim.render("cube_sea", hostsim.frame_from_oracle(f))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, stime)
+            assert np.array_equal(st, rst)
+
+
+def test_lense_blob_field_bound_holds_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_lense_field_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_lense_field_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_lense_field_bounds(3000000, 13) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    # between the fields (the bench camera), inside a field, skimming the blobs' tops, far above, and steep views
+    views = [((3.4, 0.5, 6.1), (0.0, 0.0, 0.0)), ((1.0, -5.2, 1.0), (6.0, -4.0, 7.0)), ((0.0, 3.85, 2.0), (20.0, 3.9, 9.0)), ((2.0, 900.0, 3.0), (0.0, 0.0, 0.0)),
+             ((0.5, 2.0, 0.5), (0.6, -30.0, 0.4)), ((0.2, -1.0, 8.0), (0.2, 40.0, 8.5)), ((5.0, 1500.0, 1.0), (5.0, 0.0, 1.2))]
+    for eye, at in views:
+        for stime, limits, svars in ((0.0, {}, None), (2.3, dict(max_cost_default=9, extension_lights=7), (1.5, -0.5, 9.0, 0.8))):
+            f = oracle.default_frame("lense", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=stime)
+            for k, v in limits.items():
+                setattr(f, k, v)
+            if svars:
+                for i, x in enumerate(svars):
+                    f.scene_var[i] = x
+            ref, rst, _ = oracle.render("lense", f, stats=True)
+            img, st = hostsim.render("lense", hostsim.frame_from_oracle(f))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, stime)
+            assert np.array_equal(st, rst)
+
+
+def test_terrain_octave_skip_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_terrain_octave_skip.restype = ctypes.c_longlong
+    L.hostsim_check_terrain_octave_skip.argtypes = [ctypes.c_longlong, ctypes.c_uint]
+    assert L.hostsim_check_terrain_octave_skip(2000000, 17) == 0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    views = [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((0.0, 9.0, -14.0), (0.0, 0.0, 0.0)), ((3.0, 0.7, 3.0), (-2.0, 0.4, -1.0)), ((0.5, 30.0, 0.5), (0.4, 0.0, 0.6)),
+             ((12.0, 1.0, 0.0), (0.0, 0.5, 0.0)), ((2.0, 2000.0, 2.0), (0.0, 0.0, 0.0))]
+    for eye, at in views:
+        for levels in (2, 1, 5):
+            f = oracle.default_frame("terrain", 80, 56, basis=oracle.camera_lookat(eye, at, fovy, np.float32(80.0 / 56.0)), stime=0.0)
+            f.scene_var[0] = levels
+            ref, rst, _ = oracle.render("terrain", f, stats=True)
+            img, st = hostsim.render("terrain", hostsim.frame_from_oracle(f))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, levels)
+            assert np.array_equal(st, rst)

@@ -1,0 +1,65 @@
+"""Developer tool: instruction mix of the loops of a pixel kernel (compiler's ISA, gfx950).
+
+    python tools/isa_loops.py <scene struct name, e.g. SceneCubeSea> [extra hipcc flags]
+
+Compiles the scene's group of csrc/sdfr_kernels_group.hip to assembly and lists every loop of
+k_pixel<Scene, false> with its instruction counts by issue class (tools/ubench: full rate /
+half rate / transcendental), spills and memory operations."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sdf_playground_amd", "csrc")
+HALF = ("v_min", "v_max", "v_med3", "v_floor", "v_trunc", "v_rndne", "v_fract", "v_cvt", "v_lshl", "v_lshr", "v_ashr", "v_cmp", "v_cndmask", "v_and", "v_or", "v_xor",
+        "v_bfe", "v_bfi", "v_cmpx", "v_div_", "v_ldexp", "v_frexp", "v_mul_lo", "v_mul_hi", "v_mad_u", "v_mad_i", "v_add_co", "v_addc", "v_sub_co", "v_subb", "v_readlane", "v_writelane", "v_readfirstlane")
+TRANS = ("v_rsq", "v_rcp", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")
+
+
+def main():
+    scene = sys.argv[1]
+    text = open(os.path.join(CSRC, "sdfr_perpixel.h")).read()
+    idx = int(re.search(r"X\((\d+), %s\)" % scene, text).group(1))
+    groups = int(re.search(r"#define SDFR_GROUPS (\d+)", text).group(1))
+    out = "/tmp/isa_%s.s" % scene
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-x", "hip", "-Wno-unused-result",
+           "-Wno-unknown-pragmas", "-I" + CSRC, "-DSDFR_GROUP=%d" % (idx % groups), "--cuda-device-only", "-S", os.path.join(CSRC, "sdfr_kernels_group.hip"), "-o", out] + sys.argv[2:]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4sdfr7k_pixelINS_\d+%sELb0.*:" % scene, l))
+    end = start
+    while not lines[end].startswith(".Lfunc_end"):
+        end += 1
+    body = lines[start:end]
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+    loops = set()
+    for i, l in enumerate(body):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.add((labels[m.group(1)], i))
+
+    def stats(a, b):
+        ins = [l.strip() for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
+        valu = [l for l in ins if l.startswith("v_")]
+        sgpr_operand = sum(1 for l in valu if not l.startswith(HALF + TRANS) and re.search(r"[, ]s\d+|[, ]s\[", l.split(";")[0]))
+        return dict(n=len(ins), valu=len(valu), half=sum(1 for l in valu if l.startswith(HALF)), trans=sum(1 for l in valu if l.startswith(TRANS)),
+                    sgpr_op=sgpr_operand, salu=sum(1 for l in ins if l.startswith("s_")), scratch=sum(1 for l in ins if l.startswith("scratch_")),
+                    lds=sum(1 for l in ins if l.startswith("ds_")), vmem=sum(1 for l in ins if l.startswith(("global_", "buffer_", "flat_"))))
+
+    print("%s: kernel %d lines" % (scene, len(body)))
+    print("  lines          insts  valu  (half-rate  trans  full+sgpr-operand)  salu scratch lds vmem")
+    for a, b in sorted(loops, key=lambda x: x[1] - x[0]):
+        s = stats(a, b)
+        if s["valu"] < 40:
+            continue
+        print("  %5d-%5d  %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d" % (a, b, s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"]))
+    s = stats(0, len(body) - 1)
+    print("  whole kernel   %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d" % (s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"]))
+
+
+main()

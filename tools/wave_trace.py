@@ -54,9 +54,14 @@ def main():
         rec = np.zeros((nblocks, 4), np.uint64)
         assert L.sdfr_debug_read_partials(r._h, rec.ctypes.data_as(ctypes.c_void_p), nblocks) == 0
         if k == 0:
-            continue  # warm-up
+            continue  # warm-up (and the read above has cleared the records: waves that do not exist read as zero)
+        rec = rec[(rec[:, 0] > 0) & (rec[:, 1] >= rec[:, 0])]
+        nwaves = len(rec)
         t0 = rec[:, 0].astype(np.int64)
         t1 = rec[:, 1].astype(np.int64)
+        if nwaves == 0 or (t1.max() - t0.min()) > 10_000_000:  # > 0.1 s: not a trace of one frame
+            print("frame %d: no usable trace (%d records)" % (k, nwaves))
+            continue
         base = t0.min()
         t0, t1 = (t0 - base) * 0.01, (t1 - base) * 0.01  # microseconds
         T = t1.max()
@@ -70,8 +75,9 @@ def main():
         np.add.at(d, np.minimum(t1.astype(np.int64) + 1, n), -1)
         occ = np.cumsum(d)[:n]
         peak = occ.max()
-        print("config %s frame %d: event %.3f ms; first start -> last end %.1f us; %d waves; peak resident %d; mean resident %.0f (%.2f of peak)" % (
-            a.config, k, ms, T, nblocks, peak, occ.mean(), occ.mean() / peak))
+        tiles_done = (rec[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+        print("config %s frame %d: event %.3f ms; first start -> last end %.1f us; %d waves, %d tiles (per wave min %d mean %.1f max %d); peak resident %d; mean resident %.0f (%.2f of peak)" % (
+            a.config, k, ms, T, nwaves, tiles_done.sum(), tiles_done.min(), tiles_done.mean(), tiles_done.max(), peak, occ.mean(), occ.mean() / peak))
         for frac in (0.9, 0.5, 0.25):
             below = (occ < frac * peak).sum()
             print("   time below %.0f %% of peak occupancy: %6.1f us (%.1f %% of the frame)" % (100 * frac, below, 100.0 * below / n))
@@ -84,10 +90,9 @@ def main():
         cnt = [int((xcc == x).sum()) for x in range(8)]
         print("   per-XCD last wave end (us): %s; waves per XCD: %s" % (" ".join("%.0f" % e for e in ends), cnt))
         # launch order vs start time: how far ahead of the finishing front does the dispatcher run
-        order = np.argsort(t0, kind="stable")
-        print("   start time of block index quantiles (us): %s" % " ".join("%.0f" % t0[int(p * (nblocks - 1))] for p in (0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0)))
+        print("   wave end time quantiles (us): %s" % " ".join("%.0f" % q for q in np.percentile(t1, [0, 1, 5, 25, 50, 75, 95, 99, 100])))
         late = np.argsort(t1)[-8:]
-        print("   the 8 last waves: " + "; ".join("blk %d [%.0f..%.0f] ev %d" % (b, t0[b], t1[b], int(rec[b, 3])) for b in late))
+        print("   the 8 last waves: " + "; ".join("[%.0f..%.0f] tiles %d ev %d" % (t0[b], t1[b], int(tiles_done[b]), int(rec[b, 3] >> np.uint64(32))) for b in late))
         np.savez_compressed(os.path.join(a.out, "cfg%s_frame%d.npz" % (a.config, k)), rec=rec, ms=ms)
     r.close()
 
