@@ -210,6 +210,50 @@ struct GlobalRayStore
 	}
 };
 
+// ---- fair issue among the waves of a SIMD --------------------------------------------------------------
+// A SIMD arbitrates vector issue between its waves by priority, then AGE, and ~3 waves saturate it: with
+// one workgroup per tile the oldest tiles were served first and finished; persistent waves all have the
+// same birthday, so the youngest slots of every SIMD starve (tools/wave_trace.py: waves that rendered 2
+// tiles in a whole frame while others rendered 50) and are left holding half-done tiles when the queue
+// runs dry -- a 160-us tail on a 1.4-ms frame.  The remedy is to age TILES instead: a wave raises its
+// priority (s_setprio 0..3) with the time it has spent on its current tile, one level per
+// 2^SDFR_TILE_PRIO_SHIFT ticks of the 100-MHz clock, and drops to 0 when it takes the next tile.  Checked
+// every 16th march iteration of the wave and at every tile start.  SDFR_TILE_PRIO_SHIFT 0 = off.
+#ifndef SDFR_TILE_PRIO_SHIFT
+#define SDFR_TILE_PRIO_SHIFT 11
+#endif
+struct TileAge
+{
+	unsigned long long t0;
+	uint32_t level;
+	__device__ __forceinline__ void set(uint32_t l)
+	{
+		if (l == level) return;
+		level = l;
+		switch (l) // s_setprio takes an immediate
+		{
+		case 0: __builtin_amdgcn_s_setprio(0); break;
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		default: __builtin_amdgcn_s_setprio(3); break;
+		}
+	}
+	__device__ __forceinline__ void tile_start()
+	{
+#if SDFR_TILE_PRIO_SHIFT
+		t0 = __builtin_amdgcn_s_memrealtime();
+		set(0);
+#endif
+	}
+	__device__ __forceinline__ void check()
+	{
+#if SDFR_TILE_PRIO_SHIFT
+		const uint32_t age = (uint32_t)((__builtin_amdgcn_s_memrealtime() - t0) >> SDFR_TILE_PRIO_SHIFT);
+		set(age > 3u ? 3u : age);
+#endif
+	}
+};
+
 // The pixel kernel's ray store: the write-behind cache of CachedRayStore and the pixel's ray
 // footprint, held in LDS instead of registers ([field][thread]: conflict-free).  Both live across
 // the whole bounce loop but are touched only around shading; as registers they cost 21 VGPRs at
@@ -223,7 +267,15 @@ struct LdsCachedRayStore
 	GlobalRayStore &backing;
 	lds_float *lds; // this thread's column of the block's [17][SDFR_PIXEL_BLOCK] array
 	int cached_slot;
-	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column) : backing(b), lds((lds_float *)column), cached_slot(-1) {}
+	TileAge *age;       // the wave's tile-age priority (fair issue, see TileAge)
+	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column, TileAge *a) : backing(b), lds((lds_float *)column), cached_slot(-1), age(a) {}
+	// once per march iteration of the wave; trip = the loop's trip count so far (wave-uniform)
+	__device__ __forceinline__ void tick(uint32_t trip)
+	{
+#if SDFR_TILE_PRIO_SHIFT
+		if ((trip & 15u) == 15u) age->check();
+#endif
+	}
 	__device__ __forceinline__ void write_rec(const RayRec &r)
 	{
 		lds[0 * SDFR_PIXEL_BLOCK] = r.pos.x; lds[1 * SDFR_PIXEL_BLOCK] = r.pos.y; lds[2 * SDFR_PIXEL_BLOCK] = r.pos.z;
@@ -275,47 +327,62 @@ struct LdsCachedRayStore
 };
 
 // ---- tile hand-out of the persistent pixel kernel ---------------------------------------------------
-// The launch holds exactly as many waves as the chip keeps resident; a wave renders 8x8 tiles until none
+// The launch holds about as many waves as the chip keeps resident; a wave renders 8x8 tiles until none
 // is left.  Why not one workgroup per tile: the hardware deals workgroups to the 32 shader engines in
 // strict rotation (block n -> XCD n % 8, engine (n / 8) % 4: tools/wave_trace.py shows exactly 1/32 of
 // the blocks on each), so an engine that happens to draw long-running tiles holds up the hand-out while
 // the others run dry -- 15-25 % of the wave slots stood empty through the middle of a labyrinth frame
 // (slot refill gap 9 us mean against 0.8 us while all tiles are alike).  Pulling tiles from a counter
 // has no such coupling.
-//   * the first tile of wave v is tile v: no atomic at start-up (7168 waves on one word would take ~80 us);
-//   * the other tiles are handed out through 8 cursors, 128 bytes apart (one word sustains ~88
-//     hand-outs per us, a 4K frame needs ~100): dynamic tile j belongs to cursor j % 8, a wave pulls
-//     from the cursor of its XCD and moves on to the next cursor once one has run out.  Which cursor a
-//     wave starts with is a matter of speed only: any wave may pull from any cursor.
+//   * 8 cursors, 128 bytes apart (one word sustains ~88 hand-outs per us; a 4K frame of a cheap scene
+//     needs several hundred): tile t belongs to cursor t % 8, a wave pulls from the cursor of its XCD and
+//     moves on to the next cursor once one has run out.  Which cursor a wave starts with is a matter of
+//     speed only: any wave may pull from any cursor, and a wave that starts late (the occupancy query
+//     over-states residency for some kernels) simply finds less left.
+//   * guided batches: one atomic claims up to 8 tiles of the cursor -- the share that would leave every
+//     wave of the XCD two more pulls -- and a single tile towards the end, so a cheap scene pays a handful
+//     of atomics per wave and an expensive one still ends evenly.
 //   * k_reduce_totals, which follows every launch, puts the cursors back to zero.
 #define SDFR_TILE_CURSORS 8
 #define SDFR_TILE_CURSOR_STRIDE 32 // uint32 words between two cursors
+#define SDFR_TILE_BATCH_MAX 8
 #define SDFR_NO_TILE 0xffffffffu
 struct TileQueue
 {
 	uint32_t *cursors;
-	uint32_t n_tiles, n_waves; // tiles of the launch; waves of the launch (tiles [0, n_waves) are the waves' first tiles)
+	uint32_t n_tiles, n_waves; // of the launch
 	uint32_t shard, dead;      // cursor this wave pulls from; bit s: cursor s has run out
-	__device__ __forceinline__ uint32_t first(uint32_t wave)
+	uint32_t next_k, end_k;    // claimed and not yet rendered: tiles shard + 8 k, k in [next_k, end_k)
+	__device__ __forceinline__ void start()
 	{
 		dead = 0;
+		next_k = end_k = 0;
 		shard = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (SDFR_TILE_CURSORS - 1); // HW_REG_XCC_ID
-		return wave < n_tiles ? wave : SDFR_NO_TILE;
 	}
-	// wave-uniform; one atomic by one lane per tile
+	__device__ __forceinline__ uint32_t tiles_of(uint32_t s) const { return s < n_tiles ? (n_tiles - s + SDFR_TILE_CURSORS - 1u) / SDFR_TILE_CURSORS : 0u; }
+	// wave-uniform; at most one atomic by one lane per batch
 	__device__ __forceinline__ uint32_t next()
 	{
-		if (n_tiles <= n_waves) return SDFR_NO_TILE;
-		const uint32_t dynamic = n_tiles - n_waves;
+		if (next_k < end_k) return shard + SDFR_TILE_CURSORS * next_k++;
 		while (dead != (1u << SDFR_TILE_CURSORS) - 1u)
 		{
-			const uint32_t in_shard = shard < dynamic ? (dynamic - shard + SDFR_TILE_CURSORS - 1u) / SDFR_TILE_CURSORS : 0u;
+			const uint32_t in_shard = tiles_of(shard);
+			// what is left of this cursor as far as this wave knows (end_k = where its last batch ended)
+			const uint32_t left = in_shard > end_k ? in_shard - end_k : 0u;
+			uint32_t want = left / (n_waves / SDFR_TILE_CURSORS * 2u + 1u);
+			want = want < 1u ? 1u : (want > SDFR_TILE_BATCH_MAX ? SDFR_TILE_BATCH_MAX : want);
 			uint32_t k = 0;
-			if ((threadIdx.x & 63u) == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, 1u) : 0u;
+			if ((threadIdx.x & 63u) == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, want) : 0u;
 			k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-			if (k < in_shard) return n_waves + shard + SDFR_TILE_CURSORS * k;
+			if (k < in_shard)
+			{
+				next_k = k + 1u;
+				end_k = k + want < in_shard ? k + want : in_shard;
+				return shard + SDFR_TILE_CURSORS * k;
+			}
 			dead |= 1u << shard;
 			shard = (shard + 1u) & (SDFR_TILE_CURSORS - 1u);
+			next_k = end_k = 0;
 		}
 		return SDFR_NO_TILE;
 	}
@@ -330,29 +397,30 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	// the fold kernel that follows adds into the totals: clear them here (kernel boundary = ordering)
 	if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = 0ull;
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
-	// the lane's running counters over its tiles (pixels, rays, march evaluations, hits) live in LDS as well:
-	// they are touched once per pixel, and as registers they would be live across the whole bounce loop
-	__shared__ uint32_t lds_counts[4][SDFR_PIXEL_BLOCK];
-	typedef __attribute__((address_space(3))) uint32_t lds_u32;
-	lds_u32 *counts = (lds_u32 *)&lds_counts[0][threadIdx.x];
-	counts[0 * SDFR_PIXEL_BLOCK] = 0u; counts[1 * SDFR_PIXEL_BLOCK] = 0u; counts[2 * SDFR_PIXEL_BLOCK] = 0u; counts[3 * SDFR_PIXEL_BLOCK] = 0u;
 #ifdef SDFR_WAVE_TRACE
 	const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
 	uint32_t trace_tiles = 0;
 #endif
 	const uint32_t waves_per_block = SDFR_PIXEL_BLOCK / 64u;
-	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u};
+	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u, 0u, 0u};
+	tiles.start();
+	TileAge age = {0ull, 0u};
 #ifdef SDFR_PHASE_CLOCKS
 	PixelCounters clk = {};
 #endif
-	for (uint32_t tile = tiles.first(blockIdx.x * waves_per_block + (threadIdx.x >> 6)); tile != SDFR_NO_TILE; tile = tiles.next())
+	// the wave's running counters over its tiles: summed over the lanes after every tile (a handful of
+	// shuffles per tile) and kept wave-uniform, so that no lane carries them through the bounce loop
+	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0;
+	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
+		age.tile_start();
+		PixelCounters pcnt = {};
+		uint32_t pix = 0;
 		PixelCoord pc;
 		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc))
 		{
-			PixelCounters pcnt = {};
 			GlobalRayStore backing = {ray_queue, cap, pc.pid};
-			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
+			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x], &age);
 			vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, pcnt, store);
 			store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
 			if (pixel_stats)
@@ -361,14 +429,23 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 				pixel_stats[3 * (size_t)pc.pid + 1] = pcnt.march_evals;
 				pixel_stats[3 * (size_t)pc.pid + 2] = pcnt.hits;
 			}
-			counts[0 * SDFR_PIXEL_BLOCK] += 1u;
-			counts[1 * SDFR_PIXEL_BLOCK] += pcnt.rays;
-			counts[2 * SDFR_PIXEL_BLOCK] += pcnt.march_evals;
-			counts[3 * SDFR_PIXEL_BLOCK] += pcnt.hits;
+			pix = 1;
 #ifdef SDFR_PHASE_CLOCKS
 			clk.clk_march += pcnt.clk_march; clk.clk_grad += pcnt.clk_grad; clk.clk_shade += pcnt.clk_shade; clk.clk_miss += pcnt.clk_miss; clk.clk_total += pcnt.clk_total;
 #endif
 		}
+		uint32_t a = pix, b = pcnt.rays, c = pcnt.march_evals, d = pcnt.hits;
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			a += __shfl_xor(a, off);
+			b += __shfl_xor(b, off);
+			c += __shfl_xor(c, off);
+			d += __shfl_xor(d, off);
+		}
+		w_pixels += (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+		w_rays += (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+		w_evals += (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
 #ifdef SDFR_WAVE_TRACE
 		trace_tiles++;
 #endif
@@ -377,8 +454,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	// developer build (tools/wave_trace.py): the per-block record carries when and where the wave ran
 	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, tiles | march evaluations << 32
 	{
-		uint32_t ev = counts[2 * SDFR_PIXEL_BLOCK];
-		for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+		const uint32_t ev = w_evals;
 		if (threadIdx.x == 0)
 		{
 			unsigned long long *rec = reinterpret_cast<unsigned long long *>(&partials[blockIdx.x]);
@@ -404,7 +480,9 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		return;
 	}
 #endif
-	block_store_totals(partials, counts[0 * SDFR_PIXEL_BLOCK], counts[1 * SDFR_PIXEL_BLOCK], counts[2 * SDFR_PIXEL_BLOCK], counts[3 * SDFR_PIXEL_BLOCK]);
+	// the wave's sums are uniform: lane 0 of each wave speaks for it
+	const bool speaks = (threadIdx.x & 63u) == 0;
+	block_store_totals(partials, speaks ? w_pixels : 0u, speaks ? w_rays : 0u, speaks ? w_evals : 0u, speaks ? w_hits : 0u);
 }
 
 } // namespace sdfr

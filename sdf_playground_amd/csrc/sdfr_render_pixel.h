@@ -34,6 +34,7 @@ struct CachedRayStore
 	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
 	SDF_HD void keep_pixel_ray(const PixelRay &pr) { kept = pr; }
 	SDF_HD PixelRay pixel_ray_kept() const { return kept; }
+	SDF_HD void tick(uint32_t) {} // the pixel kernel's store ages its tile here (issue fairness)
 	SDF_HD void put(int i, const RayRec &r)
 	{
 		if (cached_slot >= 0) backing.put(cached_slot, cached);
@@ -120,9 +121,11 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		SDFR_CLK(c0);
 		March m = march_begin(ray.pos, ray.dir);
 		int status;
+		uint32_t trip = 0; // of this loop: the same for every lane still in it
 		do
 		{
 			march_pre(m);
+			store.tick(trip++);
 			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
 			cnt.march_evals++;
 			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);

@@ -28,7 +28,7 @@ def test_cpp_host_mirror_reproduces_golden(tmp_path):
         args = [exe, scene, repr(float(g["stime"])), str(int(g["width"])), out] + [repr(float(x)) for x in g["eye"]] + \
                [repr(float(x)) for x in g["target"]] + ["1" if bool(g["target_is_direction"]) else "0"]
         env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-        r = subprocess.run(args, capture_output=True, text=True, env=env)
+        r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
         img = np.fromfile(out, np.float32).reshape(g["rgba"].shape)
         assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32)), scene
@@ -55,7 +55,7 @@ def test_cpp_host_compiles_a_scene_file_at_run_time(tmp_path):
     out = str(tmp_path / "img.raw")
     args = [exe, src, repr(float(g["stime"])), str(int(g["width"])), out] + [repr(float(x)) for x in g["eye"]] + [repr(float(x)) for x in g["target"]]
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run(args, capture_output=True, text=True, env=env)
+    r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     img = np.fromfile(out, np.float32).reshape(g["rgba"].shape)
     assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32))
