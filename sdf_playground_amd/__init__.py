@@ -25,6 +25,7 @@ LIB_PATH = os.environ.get("SDFR_LIBRARY") or os.path.join(_HERE, "libsdfr.so")  
 SDFR_OK = 0
 SCHEDULE_WAVEFRONT = 0
 SCHEDULE_PIXEL = 1
+LAUNCH_AUTO, LAUNCH_PER_TILE, LAUNCH_PERSISTENT = 0, 1, 2
 RGBA32F = 0
 RGBA16F = 1
 STRIP_RGB32F_A8 = 2  # strips only: rgb float triples + one flag byte per pixel (lossless, 13 B/pixel)
@@ -75,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_rank", "sdfr_comm_world",
-    "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all",
+    "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode",
 ]
 
 _lib = None
@@ -131,6 +132,7 @@ def load_library():
     L.sdfr_set_limits.argtypes = [vp, ctypes.POINTER(Limits)]
     L.sdfr_set_schedule.argtypes = [vp, ci]
     L.sdfr_set_profiling.argtypes = [vp, ci]
+    L.sdfr_set_launch_mode.argtypes = [vp, ci]
     L.sdfr_strip_buffer_pixels.argtypes = [ci, ci, ci]
     L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
     L.sdfr_strip_buffer_bytes.argtypes = [ci, ci, ci, ci]
@@ -364,6 +366,10 @@ class SDFRenderer:
 
     def setSchedule(self, schedule):
         self._check(self._L.sdfr_set_schedule(self._h, int(schedule)))
+
+    def setLaunchMode(self, mode):
+        """LAUNCH_AUTO (the scene's own choice), LAUNCH_PER_TILE or LAUNCH_PERSISTENT (sdfr_set_launch_mode)."""
+        self._check(self._L.sdfr_set_launch_mode(self._h, int(mode)))
 
     def setProfiling(self, enabled):
         self._check(self._L.sdfr_set_profiling(self._h, 1 if enabled else 0))

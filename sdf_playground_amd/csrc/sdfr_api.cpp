@@ -421,6 +421,13 @@ int sdfr_set_profiling(sdfr_renderer *r, int enabled)
 	return SDFR_OK;
 }
 
+int sdfr_set_launch_mode(sdfr_renderer *r, int mode)
+{
+	if (!r || mode < SDFR_LAUNCH_AUTO || mode > SDFR_LAUNCH_PERSISTENT) return SDFR_ERR_INVALID_ARGUMENT;
+	r->launch_mode = mode;
+	return SDFR_OK;
+}
+
 int sdfr_set_schedule(sdfr_renderer *r, int schedule)
 {
 	if (!r || (schedule != SDFR_SCHEDULE_WAVEFRONT && schedule != SDFR_SCHEDULE_PIXEL)) return SDFR_ERR_INVALID_ARGUMENT;
@@ -586,12 +593,12 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	if (!r->caller_times) SDFR_HIP(hipEventRecord(r->ev_begin, r->stream));
 	if (r->scene == SDFR_SCENE_COUNT) // scenes compiled at run time exist for the PIXEL schedule only
 	{
-		e = jit_launch_pixel(r->jit, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream);
+		e = jit_launch_pixel(r->jit, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream, r->launch_mode);
 		r->last_wavefront = false;
 	}
 	else if (r->schedule == SDFR_SCHEDULE_PIXEL)
 	{
-		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream);
+		e = launch_pixel_schedule(r->scene, r->U, rm, d_out, format, d_pstat, totals, r->ws, r->stream, r->launch_mode);
 		r->last_wavefront = false;
 	}
 	else

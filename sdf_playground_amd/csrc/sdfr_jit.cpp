@@ -194,7 +194,7 @@ hipError_t jit_prepare(const JitScene &js, FrameU &U, hipStream_t stream)
 }
 
 hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 {
 	uint32_t n_work = launch_work_items(U.width, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
@@ -204,18 +204,20 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	int per_cu = 0, device = 0;
 	if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)bt, 0) != hipSuccess || per_cu < 1) per_cu = 1;
 	(void)hipGetDevice(&device);
+	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, false); // a run-time scene: one wave per tile unless asked otherwise
+	if (mode.blocks_per_cu > 0 && mode.blocks_per_cu < per_cu) per_cu = mode.blocks_per_cu;
 	uint32_t blocks = (uint32_t)(device_cu_count(device) * per_cu);
-	if (blocks > (n_work + bt - 1u) / bt) blocks = (n_work + bt - 1u) / bt;
+	if (blocks > (n_work + bt - 1u) / bt || !mode.persistent) blocks = (n_work + bt - 1u) / bt;
 	FrameU frame = U;
 	RowMap rows = rm;
 	float *queue = ws.ray_queue;
 	size_t cap = ws.capacity;
 	RenderTotals *partials = ws.partials;
-	uint32_t *cursors = ws.tile_cursors;
+	uint32_t *cursors = mode.persistent ? ws.tile_cursors : nullptr;
 	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap, &cursors};
 	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
-	return launch_reduce_totals(partials, blocks, totals, stream, cursors);
+	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors);
 }
 
 } // namespace sdfr

@@ -30,6 +30,6 @@ void jit_unload(JitScene &js);
 hipError_t jit_prepare(const JitScene &js, FrameU &U, hipStream_t stream);
 
 hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream);
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode = 0);
 
 } // namespace sdfr

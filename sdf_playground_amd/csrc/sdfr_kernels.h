@@ -26,7 +26,7 @@ struct WavefrontWorkspace
 };
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream);
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode = 0);
 
 hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
@@ -46,8 +46,12 @@ hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_w
 
 // folds the per-block partial sums of a pixel-schedule launch into `totals` and puts the tile cursors back to zero
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors);
-// resident blocks of the device for a kernel whose occupancy query says `blocks_per_cu`
 int pixel_tile_cursor_words();
+// how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per
+// tile.  launch_mode: 0 = the scene's own default (PersistentTiles), 1 = one wave per tile, 2 = persistent;
+// the developer knobs SDFR_PIXEL_PERSISTENT=0|1 and SDFR_PIXEL_BLOCKS_PER_CU=n (cap of a persistent grid) override.
+struct PixelLaunchMode { bool persistent; int blocks_per_cu; };
+PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent);
 
 int pixel_block_threads(); // block size of the pixel kernels (partials are sized by it)
 int device_cu_count(int device);

@@ -25,6 +25,8 @@
 // Everything wave-uniform (camera, variables, limits, per-frame scene constants) travels as
 // a by-value kernel argument and therefore sits in SGPRs.
 #include "sdfr_kernels.h"
+
+#include <cstdlib>
 #include "sdfr_perpixel.h"
 #include "sdfr_pixel_kernel.h"
 
@@ -83,6 +85,17 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 	if (threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(totals) + threadIdx.x, acc[threadIdx.x]);
 }
 int pixel_tile_cursor_words() { return SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE; }
+
+PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent)
+{
+	static const int env_persistent = [] { const char *e = getenv("SDFR_PIXEL_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+	static const int env_blocks = [] { const char *e = getenv("SDFR_PIXEL_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+	PixelLaunchMode m;
+	m.persistent = launch_mode == 2 || (launch_mode == 0 && scene_default_persistent);
+	if (env_persistent >= 0) m.persistent = env_persistent != 0;
+	m.blocks_per_cu = env_blocks;
+	return m;
+}
 
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors)
 {
@@ -250,19 +263,19 @@ int device_cu_count(int device)
 
 // the per-scene launchers live in SDFR_GROUPS translation units (sdfr_kernels_group.hip); scene i is in group i % SDFR_GROUPS
 #define SDFR_DECLARE_GROUP(G) \
-	hipError_t launch_pixel_group##G(int, const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t); \
+	hipError_t launch_pixel_group##G(int, const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, int); \
 	hipError_t launch_wavefront_group##G(int, const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, \
 		hipEvent_t *, hipEvent_t *, int *);
 SDFR_FOR_EACH_GROUP(SDFR_DECLARE_GROUP)
 #undef SDFR_DECLARE_GROUP
 
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 {
 	if (scene < 0 || scene >= SDFR_SCENE_COUNT) return hipErrorInvalidValue;
 	switch (scene % SDFR_GROUPS)
 	{
-#define SDFR_CALL_GROUP(G) case G: return launch_pixel_group##G(scene, U, rows, out, format, pixel_stats, totals, ws, stream);
+#define SDFR_CALL_GROUP(G) case G: return launch_pixel_group##G(scene, U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode);
 		SDFR_FOR_EACH_GROUP(SDFR_CALL_GROUP)
 #undef SDFR_CALL_GROUP
 	default: return hipErrorInvalidValue;

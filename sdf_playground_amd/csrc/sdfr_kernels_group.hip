@@ -270,7 +270,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 // =================================================================================================
 template <class Scene, bool DBG>
 static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-	const WavefrontWorkspace &ws, hipStream_t stream)
+	const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 {
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
@@ -287,10 +287,13 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	int device = 0;
 	(void)hipGetDevice(&device);
 	const uint32_t tiles_blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
-	uint32_t blocks = (uint32_t)(device_cu_count(device) * blocks_per_cu);
-	if (blocks > tiles_blocks) blocks = tiles_blocks;
+	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, PersistentTiles<Scene>::value);
+	uint32_t per_cu = (uint32_t)blocks_per_cu;
+	if (mode.blocks_per_cu > 0 && (uint32_t)mode.blocks_per_cu < per_cu) per_cu = (uint32_t)mode.blocks_per_cu;
+	uint32_t blocks = (uint32_t)device_cu_count(device) * per_cu;
+	if (blocks > tiles_blocks || !mode.persistent) blocks = tiles_blocks;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, totals,
-		ws.ray_queue, ws.capacity, ws.tile_cursors);
+		ws.ray_queue, ws.capacity, mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr);
 	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors);
 }
 
@@ -346,7 +349,7 @@ static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, in
 template <class Scene, bool InGroup>
 struct GroupRunner
 {
-	static hipError_t pixel(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t) { return hipErrorInvalidValue; }
+	static hipError_t pixel(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, int) { return hipErrorInvalidValue; }
 	static hipError_t wavefront(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, hipEvent_t *,
 		hipEvent_t *, int *)
 	{
@@ -357,10 +360,10 @@ template <class Scene>
 struct GroupRunner<Scene, true>
 {
 	static hipError_t pixel(const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-		const WavefrontWorkspace &ws, hipStream_t stream)
+		const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 	{
-		return frame_needs_debug(U) ? run_pixel<Scene, true>(U, rows, out, format, pixel_stats, totals, ws, stream)
-									: run_pixel<Scene, false>(U, rows, out, format, pixel_stats, totals, ws, stream);
+		return frame_needs_debug(U) ? run_pixel<Scene, true>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode)
+									: run_pixel<Scene, false>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode);
 	}
 	static hipError_t wavefront(const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
 		const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events, int *n_rounds_out)
@@ -374,11 +377,11 @@ struct GroupRunner<Scene, true>
 #define SDFR_CAT(a, b) SDFR_CAT2(a, b)
 
 hipError_t SDFR_CAT(launch_pixel_group, SDFR_GROUP)(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream)
+	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 {
 	switch (scene)
 	{
-#define SDFR_RUN(I, S) case I: return GroupRunner<S, (I) % SDFR_GROUPS == SDFR_GROUP>::pixel(U, rows, out, format, pixel_stats, totals, ws, stream);
+#define SDFR_RUN(I, S) case I: return GroupRunner<S, (I) % SDFR_GROUPS == SDFR_GROUP>::pixel(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode);
 		SDFR_FOR_EACH_SCENE(SDFR_RUN)
 #undef SDFR_RUN
 	default: return hipErrorInvalidValue;

@@ -210,48 +210,12 @@ struct GlobalRayStore
 	}
 };
 
-// ---- fair issue among the waves of a SIMD --------------------------------------------------------------
-// A SIMD arbitrates vector issue between its waves by priority, then AGE, and ~3 waves saturate it: with
-// one workgroup per tile the oldest tiles were served first and finished; persistent waves all have the
-// same birthday, so the youngest slots of every SIMD starve (tools/wave_trace.py: waves that rendered 2
-// tiles in a whole frame while others rendered 50) and are left holding half-done tiles when the queue
-// runs dry -- a 160-us tail on a 1.4-ms frame.  The remedy is to age TILES instead: a wave raises its
-// priority (s_setprio 0..3) with the time it has spent on its current tile, one level per
-// 2^SDFR_TILE_PRIO_SHIFT ticks of the 100-MHz clock, and drops to 0 when it takes the next tile.  Checked
-// every 16th march iteration of the wave and at every tile start.  SDFR_TILE_PRIO_SHIFT 0 = off.
-#ifndef SDFR_TILE_PRIO_SHIFT
-#define SDFR_TILE_PRIO_SHIFT 11
-#endif
-struct TileAge
+// when the wave took its current tile (100-MHz clock): how long a tile takes decides how many the next atomic claims
+struct TileTimer
 {
 	unsigned long long t0;
-	uint32_t level;
-	__device__ __forceinline__ void set(uint32_t l)
-	{
-		if (l == level) return;
-		level = l;
-		switch (l) // s_setprio takes an immediate
-		{
-		case 0: __builtin_amdgcn_s_setprio(0); break;
-		case 1: __builtin_amdgcn_s_setprio(1); break;
-		case 2: __builtin_amdgcn_s_setprio(2); break;
-		default: __builtin_amdgcn_s_setprio(3); break;
-		}
-	}
-	__device__ __forceinline__ void tile_start()
-	{
-#if SDFR_TILE_PRIO_SHIFT
-		t0 = __builtin_amdgcn_s_memrealtime();
-		set(0);
-#endif
-	}
-	__device__ __forceinline__ void check()
-	{
-#if SDFR_TILE_PRIO_SHIFT
-		const uint32_t age = (uint32_t)((__builtin_amdgcn_s_memrealtime() - t0) >> SDFR_TILE_PRIO_SHIFT);
-		set(age > 3u ? 3u : age);
-#endif
-	}
+	__device__ __forceinline__ void tile_start() { t0 = __builtin_amdgcn_s_memrealtime(); }
+	__device__ __forceinline__ uint32_t ticks_since_start() const { return (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0); }
 };
 
 // The pixel kernel's ray store: the write-behind cache of CachedRayStore and the pixel's ray
@@ -267,15 +231,7 @@ struct LdsCachedRayStore
 	GlobalRayStore &backing;
 	lds_float *lds; // this thread's column of the block's [17][SDFR_PIXEL_BLOCK] array
 	int cached_slot;
-	TileAge *age;       // the wave's tile-age priority (fair issue, see TileAge)
-	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column, TileAge *a) : backing(b), lds((lds_float *)column), cached_slot(-1), age(a) {}
-	// once per march iteration of the wave; trip = the loop's trip count so far (wave-uniform)
-	__device__ __forceinline__ void tick(uint32_t trip)
-	{
-#if SDFR_TILE_PRIO_SHIFT
-		if ((trip & 15u) == 15u) age->check();
-#endif
-	}
+	__device__ __forceinline__ LdsCachedRayStore(GlobalRayStore &b, float *column) : backing(b), lds((lds_float *)column), cached_slot(-1) {}
 	__device__ __forceinline__ void write_rec(const RayRec &r)
 	{
 		lds[0 * SDFR_PIXEL_BLOCK] = r.pos.x; lds[1 * SDFR_PIXEL_BLOCK] = r.pos.y; lds[2 * SDFR_PIXEL_BLOCK] = r.pos.z;
@@ -339,13 +295,18 @@ struct LdsCachedRayStore
 //     moves on to the next cursor once one has run out.  Which cursor a wave starts with is a matter of
 //     speed only: any wave may pull from any cursor, and a wave that starts late (the occupancy query
 //     over-states residency for some kernels) simply finds less left.
-//   * guided batches: one atomic claims up to 8 tiles of the cursor -- the share that would leave every
-//     wave of the XCD two more pulls -- and a single tile towards the end, so a cheap scene pays a handful
-//     of atomics per wave and an expensive one still ends evenly.
+//   * one tile per atomic, unless tiles are cheap: a wave whose last tile took less than 10 us doubles its
+//     claim (up to SDFR_TILE_BATCH_MAX tiles per atomic) and falls back to one as soon as a tile takes
+//     longer.  A 4K frame of fast_sphere hands out 500 tiles per us, more than the cursors sustain one by
+//     one; but a wave must never sit on several EXPENSIVE tiles: with claims of 8 the last waves of a
+//     labyrinth frame held 8 tiles each and the frame took 1.6 instead of 1.35 ms.
 //   * k_reduce_totals, which follows every launch, puts the cursors back to zero.
 #define SDFR_TILE_CURSORS 8
 #define SDFR_TILE_CURSOR_STRIDE 32 // uint32 words between two cursors
+#ifndef SDFR_TILE_BATCH_MAX
 #define SDFR_TILE_BATCH_MAX 8
+#endif
+#define SDFR_TILE_FAST_TICKS 1000u // of the 100-MHz clock: a tile rendered this quickly (10 us) makes the wave claim more at once
 #define SDFR_NO_TILE 0xffffffffu
 struct TileQueue
 {
@@ -353,24 +314,36 @@ struct TileQueue
 	uint32_t n_tiles, n_waves; // of the launch
 	uint32_t shard, dead;      // cursor this wave pulls from; bit s: cursor s has run out
 	uint32_t next_k, end_k;    // claimed and not yet rendered: tiles shard + 8 k, k in [next_k, end_k)
-	__device__ __forceinline__ void start()
+	uint32_t batch;            // tiles the next atomic claims
+	uint32_t own_tile;         // one-wave-per-tile launches (cursors == nullptr): this wave's tile
+	__device__ __forceinline__ void start(uint32_t wave)
 	{
+		own_tile = wave < n_tiles ? wave : SDFR_NO_TILE;
 		dead = 0;
 		next_k = end_k = 0;
+		batch = 1;
 		shard = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (SDFR_TILE_CURSORS - 1); // HW_REG_XCC_ID
 	}
 	__device__ __forceinline__ uint32_t tiles_of(uint32_t s) const { return s < n_tiles ? (n_tiles - s + SDFR_TILE_CURSORS - 1u) / SDFR_TILE_CURSORS : 0u; }
+	// how long the last tile took decides how many tiles the next atomic claims
+	__device__ __forceinline__ void tile_took(uint32_t ticks)
+	{
+		batch = ticks < SDFR_TILE_FAST_TICKS ? (batch * 2u > SDFR_TILE_BATCH_MAX ? (uint32_t)SDFR_TILE_BATCH_MAX : batch * 2u) : 1u;
+	}
 	// wave-uniform; at most one atomic by one lane per batch
 	__device__ __forceinline__ uint32_t next()
 	{
+		if (!cursors) // one wave per tile (the launch has as many waves as tiles): wave v renders tile v
+		{
+			const uint32_t v = dead ? SDFR_NO_TILE : own_tile;
+			dead = 1;
+			return v;
+		}
 		if (next_k < end_k) return shard + SDFR_TILE_CURSORS * next_k++;
 		while (dead != (1u << SDFR_TILE_CURSORS) - 1u)
 		{
 			const uint32_t in_shard = tiles_of(shard);
-			// what is left of this cursor as far as this wave knows (end_k = where its last batch ended)
-			const uint32_t left = in_shard > end_k ? in_shard - end_k : 0u;
-			uint32_t want = left / (n_waves / SDFR_TILE_CURSORS * 2u + 1u);
-			want = want < 1u ? 1u : (want > SDFR_TILE_BATCH_MAX ? SDFR_TILE_BATCH_MAX : want);
+			const uint32_t want = batch;
 			uint32_t k = 0;
 			if ((threadIdx.x & 63u) == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, want) : 0u;
 			k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
@@ -402,9 +375,9 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	uint32_t trace_tiles = 0;
 #endif
 	const uint32_t waves_per_block = SDFR_PIXEL_BLOCK / 64u;
-	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u, 0u, 0u};
-	tiles.start();
-	TileAge age = {0ull, 0u};
+	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u, 0u, 0u, 1u, 0u};
+	tiles.start(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
+	TileTimer age = {0ull};
 #ifdef SDFR_PHASE_CLOCKS
 	PixelCounters clk = {};
 #endif
@@ -420,7 +393,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc))
 		{
 			GlobalRayStore backing = {ray_queue, cap, pc.pid};
-			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x], &age);
+			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
 			vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, pcnt, store);
 			store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
 			if (pixel_stats)
@@ -446,6 +419,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		w_rays += (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
 		w_evals += (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+		tiles.tile_took(age.ticks_since_start());
 #ifdef SDFR_WAVE_TRACE
 		trace_tiles++;
 #endif

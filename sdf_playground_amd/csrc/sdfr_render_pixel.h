@@ -34,7 +34,6 @@ struct CachedRayStore
 	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
 	SDF_HD void keep_pixel_ray(const PixelRay &pr) { kept = pr; }
 	SDF_HD PixelRay pixel_ray_kept() const { return kept; }
-	SDF_HD void tick(uint32_t) {} // the pixel kernel's store ages its tile here (issue fairness)
 	SDF_HD void put(int i, const RayRec &r)
 	{
 		if (cached_slot >= 0) backing.put(cached_slot, cached);
@@ -65,6 +64,19 @@ template <class Scene>
 struct ShadowHitsNeedNormal<Scene, typename VoidOf<decltype(Scene::shadow_hits_need_normal)>::type>
 {
 	static constexpr bool value = Scene::shadow_hits_need_normal;
+};
+
+// How a scene's pixel kernel is launched by default (sdfr_set_launch_mode(AUTO)): a scene that declares
+// `persistent_tiles = true` gets the persistent launch (resident waves pull tiles, TileQueue), the others one
+// wave per tile.  Measured per scene on MI355X at 3840x2160 (profiles/r02_launch_modes.txt): the persistent
+// launch wins where tiles are expensive and uneven (labyrinth, cube_sea, fractal, lense, light_shadows, gyroid:
+// 2-6 %) and loses where they are cheap (fast_sphere +34 %: the tile cursors become the bottleneck).
+template <class Scene, class = void>
+struct PersistentTiles { static constexpr bool value = false; };
+template <class Scene>
+struct PersistentTiles<Scene, typename VoidOf<decltype(Scene::persistent_tiles)>::type>
+{
+	static constexpr bool value = Scene::persistent_tiles;
 };
 
 struct PixelCounters
@@ -121,11 +133,9 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		SDFR_CLK(c0);
 		March m = march_begin(ray.pos, ray.dir);
 		int status;
-		uint32_t trip = 0; // of this loop: the same for every lane still in it
 		do
 		{
 			march_pre(m);
-			store.tick(trip++);
 			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
 			cnt.march_evals++;
 			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);

@@ -57,6 +57,7 @@ struct SceneFastSphere
 struct SceneCubeSea
 {
 	static const char *name() { return "cube_sea"; }
+	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -164,6 +165,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
+	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_FIRE_SCROLL = 0 };
@@ -302,6 +304,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
+	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -376,6 +379,7 @@ struct SceneFractal
 struct SceneLense
 {
 	static const char *name() { return "lense"; }
+	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	// the scene's variable tags in source order; slot k of FrameU::scene_var is the k-th distinct name
 	static const char *variables()
@@ -584,6 +588,7 @@ struct SceneGems
 struct SceneLightShadows
 {
 	static const char *name() { return "light_shadows"; }
+	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	// su layout: 5 x {x, y_geometry, z, y_light} then 5 x rgb (colour of sphere i)

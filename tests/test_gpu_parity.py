@@ -377,3 +377,33 @@ def test_private_strips_plus_shared_strips_make_the_full_frame(renderer, oracle,
     finally:
         renderer.setStripSplit(0, 1)
         renderer.setSchedule(1)
+
+
+@pytest.mark.parametrize("scene", ["labyrinth", "fast_sphere", "light_shadows", "lense"])
+def test_launch_modes_give_the_same_frame(renderer, oracle, scene):
+    """one wave per tile and the persistent launch (resident waves pulling tiles from the cursors, guided
+    claims) against the oracle, on a ragged frame large enough that waves take many tiles, twice in a row
+    (the cursors must come back to zero), pixels and counters"""
+    import torch
+    import sdf_playground_amd as sp
+
+    f = _setup(renderer, oracle, scene, 0.75)
+    try:
+        assert _compare(renderer, oracle, scene, f, 1)  # AUTO
+        w, h = 1003, 517
+        want = None
+        for mode in (sp.LAUNCH_PER_TILE, sp.LAUNCH_PERSISTENT, sp.LAUNCH_AUTO):
+            renderer.setLaunchMode(mode)
+            assert _compare(renderer, oracle, scene, f, 1), mode
+            for rep in range(2):
+                img = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+                pst = torch.empty((h, w, 3), dtype=torch.int32, device="cuda")
+                renderer.render(None, w, h, out=img, pixel_stats=pst)
+                s = renderer.getStats()
+                got = (img.cpu().numpy().view(np.uint32), pst.cpu().numpy(), (s.pixels, s.rays, s.march_evals, s.hits))
+                assert got[2][0] == w * h and int(got[1][..., 0].sum()) == got[2][1] and int(got[1][..., 1].sum()) == got[2][2]
+                if want is None:
+                    want = got
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2], (mode, rep)
+    finally:
+        renderer.setLaunchMode(sp.LAUNCH_AUTO)
