@@ -12,6 +12,14 @@
 //                    LDS tiles and its result is rounded to f16 in registers -- exactly what
 //                    storing the reference's bloom2 texture does -- so bloom2 never exists.
 // Algorithmic HBM bytes per pixel: 8 + 8 (pass 1), 8 + 8 + 4 (pass 2) = 36 B.
+//
+// Where the taps are worth computing.  With the reference's arithmetic (33 taps x 4 channels, a multiply
+// and an add each: nothing may fuse) a blur costs 264 vector instructions per pixel and the kernels are
+// VALU-bound, not HBM-bound.  But the bright-pass lets through only what is brighter than 0.75, so in most
+// of a frame every staged texel is zero, and a sum of zeros is +0 whatever the weights (0 * w = +-0, and
+// +0 + -0 = +0): a block whose staged tile holds nothing but zeros writes zeros (pass 1) or goes straight
+// to the tone map (pass 2) -- the same bytes, at the speed of the memory system.  Blocks that do see light
+// run the taps as before.
 #include "sdfr_kernels.h"
 #include "sdfr_math.h"
 
@@ -75,6 +83,7 @@ __global__ __launch_bounds__(256) void k_bloom_h(const uint2 *__restrict__ scene
 	__shared__ float4 tile[256 + 2 * POST_HALO];
 	const int y = blockIdx.y;
 	const int x0 = blockIdx.x * 256;
+	int lit = 0; // does this thread stage anything but zeros (of either sign)?
 	for (int i = threadIdx.x; i < 256 + 2 * POST_HALO; i += 256)
 	{
 		const int x = x0 - POST_HALO + i;
@@ -86,13 +95,14 @@ __global__ __launch_bounds__(256) void k_bloom_h(const uint2 *__restrict__ scene
 			const float factor = sat1((sat1(brightness) - 0.75f) * 4.f);
 			c = c * factor;
 		}
+		lit |= !(c.x == 0.f && c.y == 0.f && c.z == 0.f && c.w == 0.f); // NaN counts as lit
 		tile[i] = make_float4(c.x, c.y, c.z, c.w);
 	}
-	__syncthreads();
+	const int block_lit = __syncthreads_or(lit);
 	const int x = x0 + threadIdx.x;
 	if (x >= width) return;
 	vec4 sum = V4(0.f, 0.f, 0.f, 0.f);
-	Taps<-16, 2>::run(sum, &tile[threadIdx.x + POST_HALO]);
+	if (block_lit) Taps<-16, 2>::run(sum, &tile[threadIdx.x + POST_HALO]); // else: 33 x (+0 + +-0 * w) = +0
 	bloom1[(size_t)y * width + x] = pack_half4(sum * 2.f);
 }
 
@@ -109,21 +119,23 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 	const int tx = threadIdx.x & (POST_TX - 1), ty = threadIdx.x / POST_TX; // 32 x 8
 	const int x = blockIdx.x * POST_TX + tx;
 	const int y0 = blockIdx.y * POST_TY;
+	int lit = 0;
 	for (int r = ty; r < POST_TY + 2 * POST_HALO; r += 8)
 	{
 		const int y = y0 - POST_HALO + r;
 		vec4 c = V4(0.f, 0.f, 0.f, 0.f);
 		if (x < width && y >= 0 && y < height) c = load_half4(bloom1, (size_t)y * width + x);
+		lit |= !(c.x == 0.f && c.y == 0.f && c.z == 0.f && c.w == 0.f);
 		tile[r][tx] = make_float4(c.x, c.y, c.z, c.w);
 	}
-	__syncthreads();
+	const int block_lit = __syncthreads_or(lit);
 	if (x >= width) return;
 	for (int r = ty; r < POST_TY; r += 8)
 	{
 		const int y = y0 + r;
 		if (y >= height) break;
 		vec4 sum = V4(0.f, 0.f, 0.f, 0.f);
-		Taps<-16, 2 * POST_TX>::run(sum, &tile[r + POST_HALO][tx]);
+		if (block_lit) Taps<-16, 2 * POST_TX>::run(sum, &tile[r + POST_HALO][tx]);
 		const vec4 bloom = through_half4(sum * 2.f); // the reference stores bloom2 as f16
 		const vec4 sc = load_half4(scene, (size_t)y * width + x);
 		const vec4 total = sc + bloom;

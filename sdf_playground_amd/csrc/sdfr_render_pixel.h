@@ -69,8 +69,8 @@ struct ShadowHitsNeedNormal<Scene, typename VoidOf<decltype(Scene::shadow_hits_n
 // How a scene's pixel kernel is launched by default (sdfr_set_launch_mode(AUTO)): a scene that declares
 // `persistent_tiles = true` gets the persistent launch (resident waves pull tiles, TileQueue), the others one
 // wave per tile.  Measured per scene on MI355X at 3840x2160 (profiles/r02_launch_modes.txt): the persistent
-// launch wins where tiles are expensive and uneven (labyrinth, cube_sea, fractal, lense, light_shadows, gyroid:
-// 2-6 %) and loses where they are cheap (fast_sphere +34 %: the tile cursors become the bottleneck).
+// launch wins where tiles are expensive and uneven (labyrinth, cube_sea, fractal, lense, light_shadows: 1.5-3 %)
+// and loses where they are cheap (fast_sphere +14 %, cube +33 %: the tile cursors become the bottleneck).
 template <class Scene, class = void>
 struct PersistentTiles { static constexpr bool value = false; };
 template <class Scene>

@@ -56,7 +56,6 @@ struct SceneCube
 struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
-	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}

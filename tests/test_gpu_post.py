@@ -42,6 +42,30 @@ def test_postprocess_random_images(renderer, oracle, size):
     _check(renderer, oracle, img)
 
 
+@pytest.mark.parametrize("size", [(700, 230), (256, 96), (289, 129)])
+def test_postprocess_mostly_dark_images(renderer, oracle, size):
+    """blocks whose staged tile is all zeros skip the taps (sdfr_post.hip): a few bright texels placed on and around
+    the block and halo boundaries of both passes (256-wide row segments +- 32; 32x32 tiles +- 32 rows), dark texels
+    of both signs of zero and small values the bright-pass removes"""
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    img = np.zeros((h, w, 4), np.float16)
+    img[..., :3] = (rng.random((h, w, 3)) * 0.2).astype(np.float16)  # dark: the bright-pass factor is 0
+    img[rng.random((h, w)) < 0.3] = np.float16(-0.0)
+    img[..., 3] = rng.integers(0, 2, (h, w))
+    for x in (0, 31, 32, 223, 224, 255, 256, 287, 288, 289, 511, 512, 543, 544, w - 1):
+        for y in (0, 31, 32, 63, 64, 95, 96, 127, 128, h - 1):
+            if x < w and y < h and rng.random() < 0.25:
+                img[y, x] = [float(rng.uniform(1, 40)), float(rng.uniform(0.5, 9)), float(rng.uniform(0, 3)), float(rng.integers(0, 2))]
+    _check(renderer, oracle, img)
+    # and one lone light in the middle of nothing, every other block is skipped
+    img[..., :3] = 0
+    img[h // 2, w // 2] = [30, 20, 10, 1]
+    _check(renderer, oracle, img)
+    img[...] = 0
+    _check(renderer, oracle, img)
+
+
 def test_postprocess_of_rendered_frame(renderer, oracle):
     """render (RGBA16F target) -> process, as Application::render does (Application.cpp:274-284)."""
     import torch
