@@ -161,6 +161,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipFree(r->d_stage);
 	(void)hipFree(r->d_pstat);
 	(void)hipFree(r->d_wire);
+	(void)hipFree(r->d_post_flags);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
@@ -657,8 +658,18 @@ int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_
 	if (!r || !scene_rgba16f || !bloom_scratch_rgba16f || !out_rgba8) return SDFR_ERR_INVALID_ARGUMENT;
 	if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
 	SDFR_HIP(hipSetDevice(r->device));
+	const size_t flag_bytes = postprocess_flag_bytes(width, height);
+	if (r->post_flag_bytes < flag_bytes)
+	{
+		SDFR_HIP(hipStreamSynchronize(r->stream)); // a postprocess still in flight reads the old one
+		(void)hipFree(r->d_post_flags);
+		r->d_post_flags = nullptr;
+		r->post_flag_bytes = 0;
+		SDFR_HIP(hipMalloc((void **)&r->d_post_flags, flag_bytes));
+		r->post_flag_bytes = flag_bytes;
+	}
 	SDFR_HIP(hipEventRecord(r->ev_post[0], r->stream));
-	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->stream, r->ev_post[1]);
+	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->d_post_flags, r->stream, r->ev_post[1]);
 	if (e != hipSuccess) return hip_fail(r, e, "postprocess launch");
 	SDFR_HIP(hipEventRecord(r->ev_post[2], r->stream));
 	r->have_post = true;
