@@ -113,7 +113,9 @@ int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out);
 int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *limits);
 
 /* how the pipeline stages are scheduled on the GPU (results are identical).  Default: PIXEL,
- * the faster one on every scene measured on MI355X. */
+ * the faster one on every scene measured on MI355X.  WAVEFRONT is kept as a second,
+ * differently scheduled implementation for cross-checking (2.7x slower on the headline workload); nothing
+ * selects it by itself. */
 typedef enum sdfr_schedule
 {
 	SDFR_SCHEDULE_WAVEFRONT = 0, /* rays in HBM, persistent march waves refilled by ballot, separate shade kernel */
@@ -211,7 +213,8 @@ int sdfr_comm_rank(const sdfr_comm *c);
 int sdfr_comm_world(const sdfr_comm *c);
 const char *sdfr_comm_last_error(const sdfr_comm *c);
 /* `bytes` bytes travel rank -> (rank + 1) % world -> ... on `hip_stream` (world = 1: to itself) and are
- * compared at the destination: proves that the library, the communicator and the links work.  Blocking. */
+ * compared at the destination: proves that the library, the communicator and the links work.  Blocking and
+ * collective: every rank calls it (one process per rank, or one thread per communicator of sdfr_comm_create_all). */
 int sdfr_comm_selftest(sdfr_comm *c, size_t bytes, void *hip_stream);
 int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, void *root_image, int image_format, int wire_format);
 /* the same for the n handles / communicators of ONE process (sdfr_comm_create_all), rank i = index i */

@@ -59,3 +59,19 @@ def test_cpp_host_compiles_a_scene_file_at_run_time(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     img = np.fromfile(out, np.float32).reshape(g["rgba"].shape)
     assert np.array_equal(img.view(np.uint32), g["rgba"].view(np.uint32))
+
+
+def test_cpp_host_shards_a_frame_over_its_gpus_without_pytorch(tmp_path):
+    """tests/cpp/host_gather.cpp: one C++ process, one handle + one RCCL communicator per visible device
+    (sdfr_comm_create_all), sdfr_render_gather_all; the assembled image equals a direct render (both formats,
+    with and without private strips).  On a one-GPU box that is world 1; the same binary shards over N."""
+    import sdf_playground_amd as sp
+
+    exe = str(tmp_path / "host_gather")
+    libdir = os.path.dirname(sp.LIB_PATH)
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_gather.cpp"),
+                    "-L" + libdir, "-lsdfr", "-Wl,-rpath," + libdir, "-o", exe], check=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "200", "139"], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.count("identical") == 4 and "DIFFERENT" not in r.stdout
