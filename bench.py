@@ -95,6 +95,13 @@ CONFIGS = {
               camera=_cam3, metric="Mrays/s (primary+secondary), labyrinth scene, 3840x2160",
               workload="labyrinth %dx%d, iter_count 256, reference cost rules (max_cost 7, hard shadows), 16-frame fixed-seed camera sweep "
                        "(seed 0x5DF00003), default variables"),
+    "3r": dict(key="labyrinth_4k_iter256_reflective", scene="labyrinth", width=3840, height=2160,
+               limits=dict(iter_count=256, extension_marble_reflection=0.25),
+               camera=_cam3, metric="Mrays/s (primary+secondary), labyrinth scene with reflective marble (labelled extension), 3840x2160",
+               workload="LABELLED EXTENSION, not the parity target: labyrinth %dx%d, iter_count 256, the marble of walls and vases given "
+                        "reflection_color 0.25 (the reference's labyrinth has no reflective material; BASELINE configs[2] is worded '2 reflection "
+                        "bounces': with the default cost rule a ray is reflected at most twice), hard shadows, 16-frame fixed-seed camera sweep "
+                        "(seed 0x5DF00003), default variables"),
     "4": dict(key="fractal_4k_iter512", scene="fractal", width=3840, height=2160, limits=dict(iter_count=512),
               camera=_cam4, metric="Mrays/s (primary+secondary), fractal scene, 3840x2160",
               workload="fractal %dx%d, iter_count 512 (labelled extension of the reference's 100), reference cost rules, 16-frame fixed-seed camera "
@@ -242,7 +249,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="BASELINE.json configuration (SURVEY.md 8d); 3 = the headline")
+    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="BASELINE.json configuration (SURVEY.md 8d); 3 = the headline; 3r = --variant reflective")
+    ap.add_argument("--variant", default="", choices=["", "reflective"],
+                    help="reflective: config 3 with the labelled extension 'marble reflection_color 0.25' (BASELINE configs[2] as worded); never the headline")
     ap.add_argument("--schedule", default=os.environ.get("SDFR_SCHEDULE", "auto"), choices=["auto", "wavefront", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-pass", action="store_true",
@@ -328,6 +337,11 @@ def dry_launch(a):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
+    if a.variant == "reflective":
+        if a.config != HEADLINE:
+            print("bench.py: --variant reflective belongs to --config 3", file=sys.stderr)
+            return 2
+        a.config = "3r"
     if a.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
@@ -351,6 +365,10 @@ def run(a, world):
     cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # a launcher that gives every rank its own visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank)
+    # leaves exactly one ordinal; counting devices does not initialise the GPU on this image
+    if local_rank >= max(1, torch.cuda.device_count()):
+        local_rank = 0
     distributed = world > 1 or a.force_distributed
     saved_stdout = None
     dist = None

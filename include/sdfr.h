@@ -108,6 +108,10 @@ typedef struct sdfr_limits
 	 * 1..n of the scene's map_light table (the "8 lights" variant of the lense/gems benchmark
 	 * configuration; the reference's scenes carry one light).  DESIGN.md section 2. */
 	int extension_lights;
+	/* EXTENSION, 0 = reference: reflection_color given to the labyrinth's marble (MATERIAL_MARBLE_DARK / _LIGHT).
+	 * The reference's labyrinth has no reflective material; BASELINE configs[2] is worded "2 reflection bounces":
+	 * with 0.25 and the default cost rule (a reflection costs 3 of max_cost 7) a ray is reflected at most twice. */
+	float extension_marble_reflection;
 } sdfr_limits;
 int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out);
 int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *limits);

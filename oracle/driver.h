@@ -331,6 +331,11 @@ inline float4 ps_main(const Frame &F, int px, int py, PixelStats &stats)
 			material_output.use_hdr = true;
 
 			map_material<Scene>(F, geometry_input, material_input, material_output);
+			// EXTENSION, off by default (BASELINE configs[2] as worded: "2 reflection bounces"; the reference's
+			// labyrinth has no reflective material): marble is given a reflection colour
+			if (F.extension_marble_reflection != real(0.f) &&
+				(material_output.material_id == MATERIAL_MARBLE_DARK || material_output.material_id == MATERIAL_MARBLE_LIGHT))
+				material_output.reflection_color = float3(F.extension_marble_reflection);
 
 			if (!current_ray.is_shadow_ray)
 			{

@@ -43,6 +43,7 @@ struct orc_frame
 	float debug_nx, debug_ny, debug_nz, debug_scale, debug_x, debug_y, debug_z, show_objects;
 	float scene_var[8];
 	int extension_lights; // 0..7, extension (SURVEY.md 8d cfg 5)
+	float extension_marble_reflection; // 0 = reference, extension (SURVEY.md 8d cfg 3 as worded)
 };
 
 } // extern "C"
@@ -163,6 +164,7 @@ Frame to_frame(const orc_frame &f)
 	for (int i = 0; i < MAX_SCENE_VARS; ++i)
 		F.scene_var[i] = f.scene_var[i];
 	F.extension_lights = f.extension_lights < 0 ? 0 : (f.extension_lights > 7 ? 7 : f.extension_lights);
+	F.extension_marble_reflection = f.extension_marble_reflection;
 	return F;
 }
 

@@ -39,6 +39,7 @@ class OrcFrame(ctypes.Structure):
         ("show_objects", ctypes.c_float),
         ("scene_var", ctypes.c_float * 8),
         ("extension_lights", ctypes.c_int),
+        ("extension_marble_reflection", ctypes.c_float),
     ]
 
 

@@ -53,6 +53,9 @@ struct Frame
 	// EXTENSION (not in the reference; SURVEY.md 8d cfg 5 "8 lights"): number of orbiting point
 	// lights placed in slots 1..n after the scene's map_light; 0 = reference behaviour
 	int extension_lights;
+	// EXTENSION (not in the reference; SURVEY.md 8d cfg 3 "2 reflection bounces"): the labyrinth's marble
+	// (MATERIAL_MARBLE_DARK / _LIGHT) gets this reflection_color; 0 = reference behaviour (no reflective material)
+	real extension_marble_reflection;
 };
 
 // sdf_structs.hlsl:4-21

@@ -58,7 +58,8 @@ class Limits(ctypes.Structure):
     """sdfr_limits: the driver's compile-time limits (pshader_sdf.hlsl:60-64,350) at run time."""
 
     _fields_ = [("iter_count", ctypes.c_int), ("bounce_count", ctypes.c_int), ("ray_count", ctypes.c_int), ("light_count", ctypes.c_int),
-                ("range", ctypes.c_float), ("max_cost_default", ctypes.c_int), ("extension_lights", ctypes.c_int)]
+                ("range", ctypes.c_float), ("max_cost_default", ctypes.c_int), ("extension_lights", ctypes.c_int),
+                ("extension_marble_reflection", ctypes.c_float)]
 
 
 class Stats(ctypes.Structure):

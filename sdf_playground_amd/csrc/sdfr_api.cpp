@@ -395,6 +395,7 @@ int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out)
 	out->range = r->U.range;
 	out->max_cost_default = (int)r->U.max_cost_default;
 	out->extension_lights = r->U.extension_lights;
+	out->extension_marble_reflection = r->U.extension_marble_reflection;
 	return SDFR_OK;
 }
 
@@ -403,7 +404,8 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 	if (!r || !l) return SDFR_ERR_INVALID_ARGUMENT;
 	if (l->iter_count < 1 || l->iter_count > 0xffffff || l->bounce_count < 0 || l->bounce_count > 16 || l->ray_count < 1 ||
 		l->ray_count > SDFR_MAX_RAYS || l->light_count < 0 || l->light_count > SDFR_MAX_LIGHTS || l->max_cost_default < 0 ||
-		l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1)
+		l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1 ||
+		!(l->extension_marble_reflection >= 0.f && l->extension_marble_reflection <= 1.f))
 		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
 	r->U.iter_count = l->iter_count;
 	r->U.bounce_count = l->bounce_count;
@@ -412,6 +414,7 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 	r->U.range = l->range;
 	r->U.max_cost_default = (uint32_t)l->max_cost_default;
 	r->U.extension_lights = l->extension_lights;
+	r->U.extension_marble_reflection = l->extension_marble_reflection;
 	return SDFR_OK;
 }
 

@@ -34,6 +34,9 @@ struct FrameU
 	// the host per frame (sdfr_hostframe.h).  0 = reference behaviour.
 	int extension_lights;
 	float ext_light[SDFR_MAX_LIGHTS - 1][6];
+	// EXTENSION, not in the reference (SURVEY.md 8d cfg 3 "2 reflection bounces"): reflection colour given to
+	// marble materials; 0 = reference behaviour
+	float extension_marble_reflection;
 };
 
 // One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct

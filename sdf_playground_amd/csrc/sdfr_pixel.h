@@ -283,6 +283,8 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 
 	Material m = default_material(U, hit.pos);
 	map_material<Scene, DBG>(U, F, sp, m);
+	// extension, off by default: reflective marble (sdfr_limits::extension_marble_reflection)
+	if (U.extension_marble_reflection != 0.f && (m.id == MAT_MARBLE_DARK || m.id == MAT_MARBLE_LIGHT)) m.reflection = V3s(U.extension_marble_reflection);
 
 	vec3 out = V3s(0.f);
 	if (!ray_is_shadow(ray))

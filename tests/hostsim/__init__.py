@@ -26,7 +26,7 @@ class FrameU(ctypes.Structure):
         ("debug_normal", ctypes.c_float * 3), ("debug_plane_on", ctypes.c_int), ("show_on", ctypes.c_int),
         ("ddx", ctypes.c_float), ("ddy", ctypes.c_float), ("sky_s", ctypes.c_float), ("sky_c", ctypes.c_float),
         ("su", ctypes.c_float * 48),
-        ("extension_lights", ctypes.c_int), ("ext_light", (ctypes.c_float * 6) * 7),
+        ("extension_lights", ctypes.c_int), ("ext_light", (ctypes.c_float * 6) * 7), ("extension_marble_reflection", ctypes.c_float),
     ]
 
 
@@ -54,7 +54,7 @@ def frame_from_oracle(of):
     f = FrameU()
     lib().hostsim_frame_defaults(ctypes.byref(f))
     for name in ("stime", "width", "height", "iter_count", "bounce_count", "ray_count", "light_count", "range", "max_cost_default",
-                 "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects", "extension_lights"):
+                 "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects", "extension_lights", "extension_marble_reflection"):
         setattr(f, name, getattr(of, name))
     for i in range(3):
         f.eye[i], f.front[i], f.right[i], f.top[i] = of.eye[i], of.front[i], of.right[i], of.top[i]

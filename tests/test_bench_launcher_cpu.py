@@ -49,10 +49,18 @@ def test_a_failing_rank_fails_the_parent():
     assert p.returncode != 0 and not p.stdout.strip()
 
 
+def c_ref(bench):
+    """the reflective variant is config 3 plus ONE labelled extension, and says so"""
+    a, b = bench.CONFIGS["3"], bench.CONFIGS["3r"]
+    return (b["scene"], b["width"], b["height"], b["camera"]) == (a["scene"], a["width"], a["height"], a["camera"]) and \
+        b["limits"] == dict(a["limits"], extension_marble_reflection=0.25) and "LABELLED EXTENSION" in b["workload"] and "extension" in b["metric"]
+
+
 def test_configurations_are_the_ones_survey_8d_defines():
     import bench
 
-    assert sorted(bench.CONFIGS) == ["2", "3", "4", "5", "5g"]
+    assert sorted(bench.CONFIGS) == ["2", "3", "3r", "4", "5", "5g"]
+    assert c_ref(bench)
     c = bench.CONFIGS
     assert (c["2"]["scene"], c["2"]["width"], c["2"]["height"], c["2"]["limits"]["iter_count"]) == ("cube_sea", 1920, 1080, 128)
     assert (c["3"]["scene"], c["3"]["width"], c["3"]["height"], c["3"]["limits"]) == ("labyrinth", 3840, 2160, {"iter_count": 256})
@@ -66,7 +74,7 @@ def test_configurations_are_the_ones_survey_8d_defines():
     # the full-size GPU parity test and the bench agree on the cameras (frame 5)
     import tests.test_gpu_fullsize as tf
 
-    by_scene = {cfg[0]: cfg for cfg in tf._configs()}
+    by_scene = {cfg[0]: cfg for cfg in tf._configs() if "extension_marble_reflection" not in cfg[3]}
     for k, scene in (("2", "cube_sea"), ("3", "labyrinth"), ("4", "fractal"), ("5", "lense"), ("5g", "gems")):
         kind, eye, tgt, stime = c[k]["camera"](5)
         assert by_scene[scene][4] == (kind, eye, tgt) and by_scene[scene][5] == stime and by_scene[scene][3] == c[k]["limits"]

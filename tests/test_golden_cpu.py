@@ -73,6 +73,7 @@ def test_extension_limits_and_debug_views_host_vs_oracle(oracle):
         ("fast_sphere", dict(iter_count=64, max_cost_default=2), {}),
         ("cube_sea", dict(iter_count=128, max_cost_default=6), {}),
         ("labyrinth", dict(iter_count=256), {}),
+        ("labyrinth", dict(iter_count=256, extension_marble_reflection=0.25), {}),  # BASELINE configs[2] as worded: reflective marble
         ("light_shadows", dict(ray_count=4, bounce_count=6), {}),
         ("lense", dict(max_cost_default=9), dict(scene_var=(1.5, -0.5, 9.0, 0.8))),
         ("labyrinth", {}, dict(debug_ny=1.0, debug_y=1.5, debug_scale=0.5)),

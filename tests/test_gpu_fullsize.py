@@ -33,13 +33,14 @@ def _configs():
         ("cube_sea", 1920, 1080, dict(iter_count=128, max_cost_default=6), ("dir", (3 * math.cos(t2), 4.5, 3 * math.sin(t2)),
                                                                             (math.cos(t2 + 0.6), -0.45, math.sin(t2 + 0.6))), k / 60.0, 8),
         ("labyrinth", 3840, 2160, dict(iter_count=256), ("dir", (1.5 * math.cos(t3), 5.0, 1.5 * math.sin(t3)), (math.cos(t3), -0.35, math.sin(t3))), k / 60.0, 16),
+        ("labyrinth", 3840, 2160, dict(iter_count=256, extension_marble_reflection=0.25), ("dir", (1.5 * math.cos(t3), 5.0, 1.5 * math.sin(t3)), (math.cos(t3), -0.35, math.sin(t3))), k / 60.0, 16),
         ("fractal", 3840, 2160, dict(iter_count=512), ("lookat", (2.2 * math.cos(t4), 1.6, 2.2 * math.sin(t4)), (0, 1, 0)), 0.0, 16),
         ("lense", 3840, 2160, dict(iter_count=100, max_cost_default=9, extension_lights=7), ("lookat", (7 * math.sin(ph), 0.5, 7 * math.cos(ph)), (0, 0, 0)), k / 60.0, 16),
         ("gems", 3840, 2160, dict(iter_count=100, max_cost_default=9, extension_lights=7), ("lookat", (2.5 * math.cos(t5), 2, 2.5 * math.sin(t5)), (0, 1, 0)), k / 60.0, 16),
     ]
 
 
-@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c[0])
+@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: c[0] + ("_reflective" if "extension_marble_reflection" in c[3] else ""))
 def test_full_size_config_matches_oracle_on_a_pixel_sample(oracle, cfg):
     import sdf_playground_amd as sp
     import torch

@@ -72,7 +72,8 @@ def _setup(renderer, oracle, scene, stime, limits=None, variables=None):
     renderer.setCamera(cam)
     # the C++ host camera must reproduce the oracle's (and the reference's) basis bit for bit
     assert np.array_equal(renderer.getCameraBasis().view(np.uint32), basis.view(np.uint32))
-    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0)
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0,
+                       extension_marble_reflection=0.0)
     if limits:
         renderer.setLimits(**limits)
         for k, v in limits.items():
@@ -126,6 +127,7 @@ def test_scene_parity_reference_limits(renderer, oracle, scene, stime, schedule)
     ("lense", dict(max_cost_default=9, extension_lights=7)),    # config 5 as worded: depth 4, 8 lights (queue overflow, Q4)
     ("gems", dict(max_cost_default=9, extension_lights=7)),
     ("light_shadows", dict(extension_lights=3)),                # extension slots overwrite the scene's own lights 1..3
+    ("labyrinth", dict(iter_count=256, extension_marble_reflection=0.25)),  # config 3 as worded: reflective marble, 2 bounces
 ])
 def test_scene_parity_extension_limits(renderer, oracle, scene, limits):
     f = _setup(renderer, oracle, scene, 0.5, limits=limits)

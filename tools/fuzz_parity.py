@@ -39,7 +39,8 @@ def run(cases, seed, size, scenes=None, verbose=False):
             f = po.default_frame(scene, W, H, basis=basis, stime=stime)
             limits = dict(iter_count=int(rng.choice([100, 100, 256, 37])), max_cost_default=int(rng.choice([7, 7, 9, 4])),
                           ray_count=int(rng.choice([8, 8, 3])), bounce_count=int(rng.choice([16, 16, 5])),
-                          light_count=8, range=100.0, extension_lights=int(rng.choice([0, 0, 0, 7])))
+                          light_count=8, range=100.0, extension_lights=int(rng.choice([0, 0, 0, 7])),
+                          extension_marble_reflection=float(rng.choice([0.0, 0.0, 0.0, 0.25])))
             for k, v in limits.items():
                 setattr(f, k, v)
             r.setLimits(**limits)
