@@ -250,6 +250,7 @@ struct LdsCachedRayStore
 		r.bits = __float_as_uint(lds[10 * SDFR_PIXEL_BLOCK]);
 		return r;
 	}
+	__device__ __forceinline__ void ray_marched(const RayRec &, uint32_t, int) {}
 	__device__ __forceinline__ void put(int i, const RayRec &r)
 	{
 		if (cached_slot >= 0) backing.put(cached_slot, read_rec());

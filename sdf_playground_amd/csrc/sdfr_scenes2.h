@@ -11,6 +11,7 @@ namespace sdfr {
 struct SceneCube
 {
 	static const char *name() { return "cube"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	enum { V_SIZE = 0, V_X, V_Y, V_Z, V_RED, V_GREEN, V_BLUE };
 	static const char *variables()
@@ -56,6 +57,7 @@ struct SceneCube
 struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -184,6 +186,7 @@ struct SceneBasicClouds
 struct SceneCoordinateMaterial
 {
 	static const char *name() { return "coordinate_material"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static const char *variables()
 	{
 		return "VAR_boxoffset(min = 0, max = 2, step = 0.1, start = 2) VAR_spherical(min = 0, max = 1, step = 1, start = 0) "
@@ -245,6 +248,7 @@ struct SceneCoordinateMaterial
 struct SceneDistortion
 {
 	static const char *name() { return "distortion"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -325,6 +329,7 @@ struct SceneDistortion
 struct SceneTable
 {
 	static const char *name() { return "table"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -393,6 +398,7 @@ struct SceneTable
 struct SceneSierpinski
 {
 	static const char *name() { return "sierpinski"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -448,6 +454,7 @@ struct SceneSierpinski
 struct SceneNeon
 {
 	static const char *name() { return "neon"; }
+	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables()
 	{
