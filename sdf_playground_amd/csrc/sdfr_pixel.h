@@ -13,16 +13,6 @@
 
 namespace sdfr {
 
-#if defined(SDFR_HOST_TRAIT_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
-// test build (tests/hostsim): with the check on, stopped shadow rays are shaded as the reference shades them and
-// see-through surfaces met that way are counted, so a wrong `shadow_hits_are_opaque` declaration shows
-extern bool g_sdfr_trait_check;
-extern long long g_sdfr_trait_violations;
-inline bool trait_check_on() { return g_sdfr_trait_check; }
-#else
-SDF_HD constexpr bool trait_check_on() { return false; }
-#endif
-
 // ---- pixel -> primary ray (pshader_sdf.hlsl:263-267; pixel centres as D3D rasterises the
 // full-screen quad of FullscreenQuad.cpp:52-58, row 0 = top) -------------------------------
 struct PixelRay
@@ -472,10 +462,6 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 	}
 	else
 	{
-#if defined(SDFR_HOST_TRAIT_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
-		// test build (tests/hostsim): a scene that declares shadow_hits_are_opaque must never get here with a see-through surface
-		if (m.diffuse.w < 1.f) g_sdfr_trait_violations++;
-#endif
 		// a shadow ray stopped by a see-through surface continues, tinted (pshader_sdf.hlsl:598-619)
 		if (m.diffuse.w < 1.f && depth + 2 < m.max_cost)
 		{

@@ -81,36 +81,6 @@ struct PersistentTiles<Scene, typename VoidOf<decltype(Scene::persistent_tiles)>
 	static constexpr bool value = Scene::persistent_tiles;
 };
 
-// A shadow ray that escapes adds the light it carries and nothing else (pshader_sdf.hlsl:621-626); one that is
-// stopped adds nothing unless the surface is see-through (:598-619) -- and whether it is, only the material
-// callback can tell.  A scene that declares `shadow_hits_are_opaque = true` promises that its material() never
-// lowers diffuse alpha below 1 (the fire of the labyrinth does not count: its alpha is lowered in the driver's
-// material switch, which shadow rays do not pass through -- SURVEY.md Q6), so a stopped shadow ray needs no
-// material evaluation at all.  Either way such a ray is FINISHED without shading, and the lane can take its
-// pixel's next queued ray without leaving the march loop (render_pixel).  Scenes without the declaration --
-// run-time scenes by default -- chain escaped shadow rays only.
-template <class Scene, class = void>
-struct ShadowHitsAreOpaque { static constexpr bool value = false; };
-template <class Scene>
-struct ShadowHitsAreOpaque<Scene, typename VoidOf<decltype(Scene::shadow_hits_are_opaque)>::type>
-{
-	static constexpr bool value = Scene::shadow_hits_are_opaque;
-};
-
-// does any lane of the wave (the one "lane" of a host build) say so?
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SDFR_WAVE_ANY(x) (__ballot(x) != 0ull)
-#else
-#define SDFR_WAVE_ANY(x) (x)
-#endif
-// lanes whose ray has ended wait at most this many march iterations of the wave for the next chaining point
-#ifndef SDFR_CHAIN_EVERY
-#define SDFR_CHAIN_EVERY 4
-#endif
-#ifndef SDFR_CHAIN_SHADOW_RAYS
-#define SDFR_CHAIN_SHADOW_RAYS 1 // 0: developer builds that measure what the chaining buys
-#endif
-
 struct PixelCounters
 {
 	uint32_t rays, march_evals, hits;
@@ -158,56 +128,21 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		}
 		cnt.rays++;
 
-		typename Scene::RayInv R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
-		float inside_sign = ray_inside_sign(ray);
-		float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
+		const typename Scene::RayInv R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
+		const float inside_sign = ray_inside_sign(ray);
+		const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
 
-		// The march loop of the WAVE.  A lane whose ray ends stays in it while others march; if the ray is a shadow
-		// ray that needs no shading (see ShadowHitsAreOpaque) the lane books it -- exactly what the bounce loop
-		// would do: add the carried light or nothing, count the ray -- and takes the pixel's next queued ray at the
-		// next chaining point (every SDFR_CHAIN_EVERY-th iteration, or at once when no lane is marching), so that
-		// the 6-7 shadow rays of a pixel lit by 8 lights are marched back to back instead of one per bounce with
-		// every lane waiting for the longest ray each time.  The order of pops, pushes and additions per pixel is the
-		// reference's; only when they happen changes.
 		SDFR_CLK(c0);
 		March m = march_begin(ray.pos, ray.dir);
-		int status = MARCH_CONTINUE;
-		uint32_t evals_before = cnt.march_evals;
-		bool marching = true;
-		for (uint32_t trip = 0;; ++trip)
+		int status;
+		const uint32_t evals_before = cnt.march_evals;
+		do
 		{
-			if (marching)
-			{
-				march_pre(m);
-				float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
-				cnt.march_evals++;
-				status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
-				marching = status == MARCH_CONTINUE;
-			}
-			const bool chain_point = (trip % SDFR_CHAIN_EVERY) == SDFR_CHAIN_EVERY - 1 || !SDFR_WAVE_ANY(marching);
-			if (SDFR_CHAIN_SHADOW_RAYS && !marching && chain_point && ray_is_shadow(ray) && (status == MARCH_MISS || (ShadowHitsAreOpaque<Scene>::value && !DBG && !trait_check_on())) && count > 0 &&
-				bounce + 1 < U.bounce_count)
-			{
-				store.ray_marched(ray, cnt.march_evals - evals_before, status);
-				if (status == MARCH_HIT)
-					cnt.hits++; // stopped by an opaque surface: the light does not arrive (acc + 0)
-				acc = acc + (status == MARCH_HIT ? V3s(0.f) : shade_miss<Scene>(U, ray, m.iter));
-				++bounce;
-				const int idx = queue_next(depths, U.ray_count);
-				ray = store.get(idx);
-				depths = queue_set_depth(depths, idx, RAY_DEPTH_INVALID);
-				--count;
-				cnt.rays++;
-				R = Scene::ray_setup(U, ray.dir, ray_flags(ray));
-				inside_sign = ray_inside_sign(ray);
-				max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
-				m = march_begin(ray.pos, ray.dir);
-				evals_before = cnt.march_evals;
-				status = MARCH_CONTINUE;
-				marching = true;
-			}
-			if (!SDFR_WAVE_ANY(marching)) break;
-		}
+			march_pre(m);
+			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
+			cnt.march_evals++;
+			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
+		} while (status == MARCH_CONTINUE);
 		SDFR_CLK(c1);
 		SDFR_CLK_ADD(clk_march, c0, c1);
 		store.ray_marched(ray, cnt.march_evals - evals_before, status); // a hook for analysis builds (tests/hostsim); empty in the kernels

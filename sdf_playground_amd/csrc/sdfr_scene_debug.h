@@ -13,7 +13,6 @@ namespace sdfr {
 struct SceneDebugMaterials
 {
 	static const char *name() { return "debug_materials"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };

@@ -24,7 +24,6 @@ namespace sdfr {
 struct SceneFastSphere
 {
 	static const char *name() { return "fast_sphere"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -58,7 +57,6 @@ struct SceneFastSphere
 struct SceneCubeSea
 {
 	static const char *name() { return "cube_sea"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -167,7 +165,6 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -307,7 +304,6 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -383,7 +379,6 @@ struct SceneFractal
 struct SceneLense
 {
 	static const char *name() { return "lense"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	// the scene's variable tags in source order; slot k of FrameU::scene_var is the k-th distinct name
@@ -535,7 +530,6 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
@@ -594,7 +588,6 @@ struct SceneGems
 struct SceneLightShadows
 {
 	static const char *name() { return "light_shadows"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }

@@ -11,7 +11,6 @@ namespace sdfr {
 struct SceneCube
 {
 	static const char *name() { return "cube"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	enum { V_SIZE = 0, V_X, V_Y, V_Z, V_RED, V_GREEN, V_BLUE };
 	static const char *variables()
@@ -57,7 +56,6 @@ struct SceneCube
 struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -186,7 +184,6 @@ struct SceneBasicClouds
 struct SceneCoordinateMaterial
 {
 	static const char *name() { return "coordinate_material"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static const char *variables()
 	{
 		return "VAR_boxoffset(min = 0, max = 2, step = 0.1, start = 2) VAR_spherical(min = 0, max = 1, step = 1, start = 0) "
@@ -248,7 +245,6 @@ struct SceneCoordinateMaterial
 struct SceneDistortion
 {
 	static const char *name() { return "distortion"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -329,7 +325,6 @@ struct SceneDistortion
 struct SceneTable
 {
 	static const char *name() { return "table"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -398,7 +393,6 @@ struct SceneTable
 struct SceneSierpinski
 {
 	static const char *name() { return "sierpinski"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -454,7 +448,6 @@ struct SceneSierpinski
 struct SceneNeon
 {
 	static const char *name() { return "neon"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables()
 	{

@@ -9,7 +9,6 @@ namespace sdfr {
 struct SceneFractal2
 {
 	static const char *name() { return "fractal2"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return "VAR_slider(min = -5, max = 5, step = 0.01, start = 0)"; } // declared, unused by the scene
 	enum { SU_SLICE_SHIFT = 0 };
@@ -90,7 +89,6 @@ struct SceneFractal2
 struct SceneShell
 {
 	static const char *name() { return "shell"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -139,7 +137,6 @@ struct SceneShell
 struct SceneSpiral
 {
 	static const char *name() { return "spiral"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	// a spring hopping along a parabola: everything about the hop is frame-uniform
@@ -221,7 +218,6 @@ struct SceneSpiral
 struct SceneTerrain
 {
 	static const char *name() { return "terrain"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return "VAR_levels(min=1, max=10, step=1, start=2)"; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
@@ -304,7 +300,6 @@ struct SceneTerrain
 struct SceneTiling
 {
 	static const char *name() { return "tiling"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	enum { V_M1 = 0, V_M2, V_WIDTH, V_RUN_LENGTH, V_RUN_FLIP, V_FLIP_CHANCE, V_TRUCHET_WIDTH };
 	static const char *variables()

@@ -9,7 +9,6 @@ namespace sdfr {
 struct SceneTree
 {
 	static const char *name() { return "tree"; }
-	static constexpr bool shadow_hits_are_opaque = true; // material() never lowers diffuse alpha below 1 (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_DRIFT = 0 };

@@ -2,7 +2,6 @@
 // (sdf_playground_amd/csrc/sdfr_perpixel.h) for the CPU, so that the stage arithmetic can be
 // bit-compared with the oracle in the CPU test tier, where there is no GPU.  This library is
 // never loaded by the product; the product renders on the GPU only.
-#define SDFR_HOST_TRAIT_CHECK 1
 #include "sdfr_hostframe.h"
 
 #include <atomic>
@@ -10,13 +9,6 @@
 #include <vector>
 
 using namespace sdfr;
-
-namespace sdfr {
-bool g_sdfr_trait_check = false;
-long long g_sdfr_trait_violations = 0;
-} // namespace sdfr
-extern "C" void hostsim_trait_check(int on) { g_sdfr_trait_check = on != 0; g_sdfr_trait_violations = 0; }
-extern "C" long long hostsim_trait_violations() { return g_sdfr_trait_violations; }
 
 typedef CachedRayStore<LocalRayStore> HostStore; // same store stack as the pixel kernel
 typedef vec4 (*pixel_fn)(const FrameU &, int, int, PixelCounters &, HostStore &);

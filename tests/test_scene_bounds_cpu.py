@@ -152,38 +152,3 @@ def test_terrain_octave_skip_is_invisible(oracle):
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, levels)
             assert np.array_equal(st, rst)
 
-
-def test_shadow_hits_are_opaque_where_scenes_say_so(oracle):
-    """Scenes declaring `shadow_hits_are_opaque` let the kernels finish a stopped shadow ray without evaluating the
-    material (sdfr_render_pixel.h).  With the check on, the host build shades those hits as the reference does and
-    counts every see-through surface a shadow ray meets: none for the scenes that declare it (a wrong declaration
-    would also show as a parity failure), some for basic_transparency, which does not."""
-    import golden_util as gu
-    import hostsim
-
-    L = hostsim.lib()
-    L.hostsim_trait_violations.restype = ctypes.c_longlong
-    declared = set(oracle.scene_names()) - {"basic_transparency", "basic_clouds"} | {"debug_materials"}
-    seen_control = 0
-    try:
-        for path in gu.golden_files():
-            scene = gu.scene_of(path)
-            f = gu.oracle_frame(oracle, np.load(path))
-            f.max_cost_default = 9
-            f.extension_lights = 7  # plenty of shadow rays
-            L.hostsim_trait_check(1)
-            img, st = hostsim.render(scene, hostsim.frame_from_oracle(f))
-            bad = L.hostsim_trait_violations()
-            ref, rst, _ = oracle.render(scene, f, stats=True)
-            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(st, rst), scene
-            if scene in declared:
-                assert bad == 0, (scene, bad)
-            elif scene == "basic_transparency":
-                seen_control += bad
-            # and with the shortcut taken (check off) the same bits
-            L.hostsim_trait_check(0)
-            img2, st2 = hostsim.render(scene, hostsim.frame_from_oracle(f))
-            assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32)) and np.array_equal(st2, rst), scene
-    finally:
-        L.hostsim_trait_check(0)
-    assert seen_control > 0
