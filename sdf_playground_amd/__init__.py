@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode",
+    "sdfr_register_host_target",
 ]
 
 _lib = None
@@ -134,6 +135,7 @@ def load_library():
     L.sdfr_set_schedule.argtypes = [vp, ci]
     L.sdfr_set_profiling.argtypes = [vp, ci]
     L.sdfr_set_launch_mode.argtypes = [vp, ci]
+    L.sdfr_register_host_target.argtypes = [vp, vp, ctypes.c_size_t]
     L.sdfr_strip_buffer_pixels.argtypes = [ci, ci, ci]
     L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
     L.sdfr_strip_buffer_bytes.argtypes = [ci, ci, ci, ci]
@@ -402,6 +404,17 @@ class SDFRenderer:
         self._check(self._L.sdfr_render(self._h, width, height, img.ctypes.data_as(ctypes.c_void_p), fmt, 1,
                                         st.ctypes.data_as(ctypes.c_void_p) if pixel_stats else None))
         return (img, st) if pixel_stats else img
+
+    def registerHostTarget(self, array):
+        """Page-lock a numpy image that render(out=array) will fill every frame (sdfr_register_host_target); None
+        unregisters.  The array must stay alive and unmoved while registered."""
+        if array is None:
+            self._check(self._L.sdfr_register_host_target(self._h, None, 0))
+            self._host_target = None
+        else:
+            assert array.flags["C_CONTIGUOUS"]
+            self._check(self._L.sdfr_register_host_target(self._h, array.ctypes.data_as(ctypes.c_void_p), array.nbytes))
+            self._host_target = array  # keeps it alive
 
     def setStripSplit(self, priv_count, priv_period):
         """Of every priv_period strips the first priv_count are private to the root (renderPrivateStrips),

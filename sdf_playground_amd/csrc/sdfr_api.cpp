@@ -162,6 +162,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipFree(r->d_pstat);
 	(void)hipFree(r->d_wire);
 	(void)hipFree(r->d_post_flags);
+	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
@@ -709,6 +710,21 @@ int sdfr_debug_read_partials(sdfr_renderer *r, void *host, size_t records)
 	return SDFR_OK;
 }
 #endif
+
+int sdfr_register_host_target(sdfr_renderer *r, void *host_image, size_t bytes)
+{
+	if (!r || (host_image && bytes == 0)) return SDFR_ERR_INVALID_ARGUMENT;
+	SDFR_HIP(hipSetDevice(r->device));
+	SDFR_HIP(hipStreamSynchronize(r->stream));
+	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
+	r->pinned_host = nullptr;
+	r->pinned_bytes = 0;
+	if (!host_image) return SDFR_OK;
+	SDFR_HIP(hipHostRegister(host_image, bytes, hipHostRegisterDefault));
+	r->pinned_host = host_image;
+	r->pinned_bytes = bytes;
+	return SDFR_OK;
+}
 
 int sdfr_sync(sdfr_renderer *r)
 {

@@ -37,6 +37,9 @@ struct sdfr_renderer
 	size_t stage_bytes = 0;
 	uint32_t *d_pstat = nullptr;
 	size_t pstat_bytes = 0;
+	// sdfr_register_host_target: the caller's persistent host image, page-locked with the runtime
+	void *pinned_host = nullptr;
+	size_t pinned_bytes = 0;
 
 	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 	hipEvent_t ev_post[3] = {}; // before / between / after the two post-processing kernels

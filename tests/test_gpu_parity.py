@@ -409,3 +409,20 @@ def test_launch_modes_give_the_same_frame(renderer, oracle, scene):
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2], (mode, rep)
     finally:
         renderer.setLaunchMode(sp.LAUNCH_AUTO)
+
+
+def test_registered_host_target(renderer, oracle):
+    """sdfr_register_host_target: a page-locked host image is filled with the same bits, frame after frame; after
+    unregistering, ordinary host destinations still work"""
+    f = _setup(renderer, oracle, "labyrinth", 0.75)
+    ref, _, _ = oracle.render("labyrinth", f)
+    host = np.full((H, W, 4), 7.0, np.float32)
+    renderer.registerHostTarget(host)
+    try:
+        for _ in range(3):
+            host[...] = 7.0
+            renderer.render(None, W, H, out=host)
+            assert np.array_equal(host.view(np.uint32), ref.view(np.uint32))
+    finally:
+        renderer.registerHostTarget(None)
+    assert np.array_equal(renderer.render(None, W, H).view(np.uint32), ref.view(np.uint32))
