@@ -373,7 +373,13 @@ def run(a, world):
     saved_stdout = None
     dist = None
     if distributed:
+        import faulthandler
+
         import torch.distributed as dist
+
+        # a rank that hangs (a collective that never completes) must end the run, not sit in it: dump every thread's
+        # stack and exit after 10 minutes without reaching the end
+        faulthandler.dump_traceback_later(600, exit=True)
 
         # RCCL prints a version banner on stdout when the first communicator is made; the contract
         # is ONE line on stdout, so stdout points at stderr until the result line is printed
@@ -398,6 +404,10 @@ def run(a, world):
         h.initShader(scene)
         h.setLimits(**cfg["limits"])
         h.setSchedule(schedule)
+        if distributed:
+            # the persistent launch keeps every wave slot of the GPU until its frame ends; the transfer kernels of the
+            # frame before (RCCL, another stream) would wait for slots instead of overlapping: one wave per tile here
+            h.setLaunchMode(sp.LAUNCH_PER_TILE)
         if stream is not None:
             h.setStream(stream.cuda_stream)
         return h
@@ -726,6 +736,7 @@ def run(a, world):
     if distributed:
         torch.cuda.synchronize()
         dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
         for h_ in rr[1:]:
             h_.close()
         if comm is not None:
