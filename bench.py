@@ -263,9 +263,11 @@ def parse_args(argv=None):
     ap.add_argument("--private-strips", default="auto",
                     help="N > 1: of every 16 strips, how many rank 0 renders privately (its pixels do not travel); 'auto' = the fastest of a few "
                          "candidates timed during start-up")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "gloo"],
                     help="N > 1: rccl = the library's own gather (sdfr_render_gather); torch = torch.distributed.gather of the same strips "
-                         "(also taken, on every rank, when the library's communicator cannot be made)")
+                         "(also taken, on every rank, when the library's communicator cannot be made); gloo = the same strips staged "
+                         "through host memory and gathered over gloo -- slow, for rehearsing N ranks where RCCL cannot run, e.g. several "
+                         "ranks on ONE GPU (RCCL refuses two ranks on a device); never a result")
     ap.add_argument("--wire", default="f16", choices=["f16", "f32"],
                     help="N > 1: f16 = strips and image in the reference's RGBA16F target format (7 B/pixel on the links); f32 = lossless fp32 (13 B/pixel)")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="N > 1: handles / streams the frames alternate between")
@@ -392,8 +394,13 @@ def run(a, world):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.transport == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    host_staged = distributed and a.transport == "gloo"
+    ctl = "cpu" if host_staged else "cuda"   # where the control tensors of the collectives live
     W, H = a.width or cfg["width"], a.height or cfg["height"]
     scene = cfg["scene"]
     schedule = {"auto": sp.SCHEDULE_PIXEL, "wavefront": sp.SCHEDULE_WAVEFRONT, "pixel": sp.SCHEDULE_PIXEL}[a.schedule]
@@ -436,8 +443,10 @@ def run(a, world):
         rs = [stream] + [torch.cuda.Stream() for _ in range(depth - 1)]
         rr = [r] + [make_renderer(rs[b]) for b in range(1, depth)]
         transport = a.transport
-        if transport == "rccl":
-            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        if transport == "gloo":
+            transport = "gloo (strips staged through host memory: a rehearsal of the N-rank flow, not a result)"
+        if a.transport == "rccl":
+            ok = torch.ones(1, dtype=torch.int32, device=ctl)
             try:
                 ids = [sp.Comm.unique_id() if rank == 0 else None]
             except Exception as e:
@@ -499,6 +508,29 @@ def run(a, world):
             h.renderGather(comm, W, H, out=images[b] if rank == 0 else None, fmt=img_fmt, wire=wire_fmt)
             return [h]
         used = [h]
+        if host_staged:
+            # rehearsal transport: render, copy the strips to the host, gather over gloo, copy to the GPU, assemble -- one
+            # frame at a time, every step synchronous
+            with torch.cuda.stream(rs[b]):
+                h.renderStrips(W, H, rank, world, local[b], fmt=wire_fmt)
+            rs[b].synchronize()
+            mine = local[b].cpu()
+            if rank == 0:
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.gather(mine, gather_list=parts, dst=0)
+                with torch.cuda.stream(rs[b]):
+                    gathered_flat[b].copy_(torch.stack(parts))
+                    if split[0] > 0:
+                        hp = r_priv[b]
+                        hp.setParameters(stime)
+                        hp.setCamera(cam)
+                        hp.renderPrivateStrips(W, H, images[b], fmt=img_fmt)
+                        used.append(hp)
+                    r_asm.setStream(rs[b].cuda_stream)
+                    r_asm.assembleStrips(W, H, world, gathered_flat[b], images[b], fmt=wire_fmt)
+            else:
+                dist.gather(mine, dst=0)
+            return used
         with torch.cuda.stream(rs[b]):
             if works[b] is not None:
                 works[b].wait()                    # this frame's stream: local[b] is free once the gather `depth` frames ago is done
@@ -551,7 +583,7 @@ def run(a, world):
                 for s in range(6):
                     step(s)
                 fence()
-                tm = torch.tensor([(time.perf_counter() - t0c) / 6 * 1e3], dtype=torch.float64, device="cuda")
+                tm = torch.tensor([(time.perf_counter() - t0c) / 6 * 1e3], dtype=torch.float64, device=ctl)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 trials[m] = float(tm.item())
                 if best is None or trials[m] < trials[best] * 0.97:
@@ -594,12 +626,12 @@ def run(a, world):
     my_rays = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(a.steps))
     step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays_t = torch.tensor([my_rays], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
+    rays_t = torch.tensor([my_rays], dtype=torch.float64, device=ctl)
     per_rank = None
     if distributed:
-        every = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(every, torch.tensor([my_rays, elapsed], dtype=torch.float64, device="cuda"))
+        every = [torch.zeros(2, dtype=torch.float64, device=ctl) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([my_rays, elapsed], dtype=torch.float64, device=ctl))
         per_rank = [{"rank": i, "rays": float(v[0].item()), "seconds": float(v[1].item())} for i, v in enumerate(every)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)

@@ -59,3 +59,22 @@ def test_bench_other_configurations_run():
     d = _run(["--config", "2"])
     assert d["verified"] is True and d["config"]["baseline_config"] == "2" and "cube_sea" in d["metric"]
     assert d["roofline"]["flops_per_ray"] > 1000 and "ALGORITHMIC" in d["roofline"]["numerator"]
+
+
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--private-strips", "5"]), (2, ["--wire", "f32", "--frames-in-flight", "1"])])
+def test_bench_n_ranks_rehearsed_on_one_gpu(ranks, extra):
+    """`bench.py --gpus N` end to end with N real rank processes on the one GPU of the box: the script starts its own
+    ranks, every rank renders only its strips with its own handles, the strips travel (staged through host memory over
+    gloo: RCCL refuses two ranks on one device, so this rehearses everything but the RCCL transfer itself), rank 0
+    assembles; its image must equal a direct render bit for bit and the ranks' ray counters must add up to the frame's."""
+    d = _run(["--gpus", str(ranks), "--transport", "gloo"] + extra)
+    assert d["verified"] is True and d["n_gpus"] == ranks and d["config"]["parallelism"] == "strips%d" % ranks
+    per_rank = d["config"]["per_rank"]
+    assert [p["rank"] for p in per_rank] == list(range(ranks)) and all(p["rays"] > 0 for p in per_rank)
+    total = sum(p["rays"] for p in per_rank)
+    assert abs(total / d["steps"] / (328 * 205) - d["config"]["rays_per_pixel"]) < 1e-9
+    # the same frames rendered by one rank trace the same number of rays
+    assert abs(d["config"]["rays_per_pixel"] - _run([])["config"]["rays_per_pixel"]) < 1e-12
+    if "--private-strips" in extra:
+        assert d["config"]["strip_calibration"]["private_strips_of_16"] == 5
+        assert per_rank[0]["rays"] > per_rank[1]["rays"]  # rank 0 keeps 5 of every 16 strips for itself
