@@ -133,7 +133,13 @@ int gather_check(sdfr_renderer *r, const sdfr_comm *c, int width, int height, co
 int gather_render(sdfr_renderer *r, const sdfr_comm *c, const GatherShape &g)
 {
 	SDFR_HIP(hipSetDevice(r->device));
-	if (!r->comm_stream) SDFR_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+	if (!r->comm_stream)
+	{
+		// transfers and assembly go ahead of rendering waves wherever the two compete for a CU: highest priority
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+		SDFR_HIP(hipStreamCreateWithPriority(&r->comm_stream, hipStreamNonBlocking, greatest));
+	}
 	if (!r->ev_strips) SDFR_HIP(hipEventCreateWithFlags(&r->ev_strips, hipEventDisableTiming));
 	if (!r->ev_gathered) SDFR_HIP(hipEventCreateWithFlags(&r->ev_gathered, hipEventDisableTiming));
 	const size_t need = (c->rank == 0 ? (size_t)g.world : (size_t)1) * g.rank_bytes;
