@@ -163,6 +163,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipFree(r->d_wire);
 	(void)hipFree(r->d_post_flags);
 	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
+	(void)sdfr_peer_region_close(r);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);

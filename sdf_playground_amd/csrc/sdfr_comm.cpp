@@ -103,6 +103,22 @@ static int need_rccl(const sdfr_comm *c)
 	return comm_fail(c, "RCCL is not available: " + (n.why.empty() ? std::string("librccl.so not found") : n.why));
 }
 
+// the stream and events transfers and assembly run on (both transports)
+int sdfr::gather_prepare_streams(sdfr_renderer *r)
+{
+	SDFR_HIP(hipSetDevice(r->device));
+	if (!r->comm_stream)
+	{
+		// transfers and assembly go ahead of rendering waves wherever the two compete for a CU: highest priority
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+		SDFR_HIP(hipStreamCreateWithPriority(&r->comm_stream, hipStreamNonBlocking, greatest));
+	}
+	if (!r->ev_strips) SDFR_HIP(hipEventCreateWithFlags(&r->ev_strips, hipEventDisableTiming));
+	if (!r->ev_gathered) SDFR_HIP(hipEventCreateWithFlags(&r->ev_gathered, hipEventDisableTiming));
+	return SDFR_OK;
+}
+
 // ---- the three phases of a gathered frame, per rank -------------------------------------------------
 namespace {
 
@@ -132,16 +148,8 @@ int gather_check(sdfr_renderer *r, const sdfr_comm *c, int width, int height, co
 // phase 1: render this rank's shared strips into its slot of the wire buffer (handle's stream)
 int gather_render(sdfr_renderer *r, const sdfr_comm *c, const GatherShape &g)
 {
-	SDFR_HIP(hipSetDevice(r->device));
-	if (!r->comm_stream)
-	{
-		// transfers and assembly go ahead of rendering waves wherever the two compete for a CU: highest priority
-		int least = 0, greatest = 0;
-		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-		SDFR_HIP(hipStreamCreateWithPriority(&r->comm_stream, hipStreamNonBlocking, greatest));
-	}
-	if (!r->ev_strips) SDFR_HIP(hipEventCreateWithFlags(&r->ev_strips, hipEventDisableTiming));
-	if (!r->ev_gathered) SDFR_HIP(hipEventCreateWithFlags(&r->ev_gathered, hipEventDisableTiming));
+	int prc = gather_prepare_streams(r);
+	if (prc != SDFR_OK) return prc;
 	const size_t need = (c->rank == 0 ? (size_t)g.world : (size_t)1) * g.rank_bytes;
 	if (r->wire_bytes < need)
 	{

@@ -60,6 +60,14 @@ struct sdfr_renderer
 	void *d_wire = nullptr;    // this rank's compact strips; on the root: world x that, slot 0 = its own
 	size_t wire_bytes = 0;
 	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
+
+	// peer-copy gather (sdfr_peer.hip): rank 0 owns the region, the peers map it through hipIpc
+	void *peer_buffer = nullptr;    // the gathered buffer (rank 0's memory)
+	uint32_t *peer_flags = nullptr; // [0..63] arrived[rank], [64] released, [65] timed out
+	size_t peer_capacity = 0;
+	int peer_world = 0;
+	bool peer_owner = false;
+	uint32_t peer_frame = 0;        // frames gathered through this region so far
 };
 
 static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)
@@ -86,5 +94,8 @@ bool is_wire_format(int format);
 // the launch's counters (nullptr: the handle's d_totals).
 int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
 	RenderMode mode, RenderTotals *totals = nullptr);
+
+// the stream and events shared by the RCCL and the peer-copy transports of a gathered frame (sdfr_comm.cpp)
+int gather_prepare_streams(sdfr_renderer *r);
 
 } // namespace sdfr
