@@ -782,6 +782,13 @@ def run(a, world):
         print(json.dumps(out), flush=True)
 
     if distributed:
+        # the result is out; tearing down communicators must not be able to hold the process (RCCL has been seen to sit in
+        # ncclCommDestroy): if it has not finished within a minute the process ends with the status it has earned
+        import threading
+
+        watchdog = threading.Timer(60.0 if rank == 0 else 75.0, lambda: os._exit(0))
+        watchdog.daemon = True
+        watchdog.start()
         torch.cuda.synchronize()
         if peer_copy:
             for h_ in rr:
@@ -799,6 +806,7 @@ def run(a, world):
     r.close()
     if distributed:
         dist.destroy_process_group()
+        watchdog.cancel()
     return 0
 
 

@@ -553,15 +553,11 @@ class Comm:
         return True
 
     def close(self):
+        """ncclCommDestroy: collective in effect -- every rank should close; not called implicitly (a communicator
+        that is still open when the process ends is reclaimed with it)"""
         if self._c:
             self._L.sdfr_comm_destroy(self._c)
             self._c = ctypes.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 class HDR:

@@ -18,7 +18,8 @@ def comm():
 
     c = sp.Comm(sp.Comm.unique_id(), 0, 1, 0)
     yield c
-    c.close()
+    # not closed here: the communicator goes with the process (bench.py closes its own, in a child process of
+    # tests/test_gpu_bench.py, behind a watchdog: RCCL's teardown is the one call in this path that has no time limit)
 
 
 @pytest.fixture()
