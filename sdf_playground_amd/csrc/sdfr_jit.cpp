@@ -89,10 +89,10 @@ std::string jit_translation_unit(const std::string &scene_source, const std::vec
 	tu += scene_source;
 	tu += "\n#line 1 \"sdfr_jit_kernels\"\n";
 	tu += "extern \"C\" __global__ void sdfr_jit_prepare(FrameU *U) { if (blockIdx.x == 0 && threadIdx.x == 0) Scene::prepare(*U); }\n";
-	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
+	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
 		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
 		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
-	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
+	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
 		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
 		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
 	tu += "} // namespace sdfr\n";

@@ -24,7 +24,7 @@ static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_wo
 // PIXEL schedule (body: sdfr_pixel_kernel.h)
 // =================================================================================================
 template <class Scene, bool DBG>
-__global__ SDFR_PIXEL_KERNEL_ATTRS void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
+__global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)
 {
 	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors);

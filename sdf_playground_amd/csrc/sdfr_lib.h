@@ -16,6 +16,7 @@ namespace sdfr {
 
 // epsilons of the reference driver (pshader_sdf.hlsl:31-35)
 #define SDFR_DIST_EPS 0.0001f
+#define SDFR_MAX_WAVES_PER_BLOCK 4 // of any kernel that evaluates scenes (checked where the block sizes are defined): per-wave LDS of scene code
 #define SDFR_GRAD_EPS 0.0001f
 #define SDFR_REFLECT_EPS 0.001f
 #define SDFR_REFRACT_EPS 0.001f

@@ -19,6 +19,9 @@ namespace sdfr {
 #define SDFR_PIXEL_BLOCK 64
 #endif
 #define SDFR_INVALID_PIXEL 0xffffffffu
+#ifdef SDFR_MAX_WAVES_PER_BLOCK
+static_assert(SDFR_BLOCK <= 64 * SDFR_MAX_WAVES_PER_BLOCK && SDFR_PIXEL_BLOCK <= 64 * SDFR_MAX_WAVES_PER_BLOCK, "per-wave LDS of the scenes");
+#endif
 // Launch attributes of every pixel kernel.  The register allocator is held to 7 waves per SIMD
 // (<= 72 VGPRs; left alone it takes ~100-160 and fits 3-4): the VALU of gfx950 issues one
 // instruction per wave every ~8 cycles (tools/ubench: 7.5-8 cycles per instruction at 1 wave/SIMD,
@@ -28,10 +31,19 @@ namespace sdfr {
 // march loop (checked in the ISA).  8 waves (64 VGPRs, 40 spilled dwords) are no faster.
 // Measured at 4K (labyrinth / fractal / lense, ms): 3 waves 1.77 / 2.4 / 7.9 (allocator's choice),
 // 4: 1.61 / 2.2 / 7.9, 5: 1.55 / 2.16 / 7.8, 6: 1.50 / 2.25 / 8.0, 7: 1.43 / 2.03 / 7.2, 8: 1.5 / 2.1 / 7.2.
+// With the persistent launch (round 2) the headline scene no longer cares (labyrinth at 4K, ms: 3 waves 1.39, 4: 1.42,
+// 5: 1.40, 6: 1.40, 7: 1.40, 8: 1.41); scenes with very long evaluations prefer fewer waves with more registers and
+// say so with `waves_per_simd` (tree: 5), scenes whose march loop fits 64 registers can ask for 8.
 #ifndef SDFR_PIXEL_WAVES_PER_EU
 #define SDFR_PIXEL_WAVES_PER_EU 7
 #endif
-#define SDFR_PIXEL_KERNEL_ATTRS __launch_bounds__(SDFR_PIXEL_BLOCK) __attribute__((amdgpu_waves_per_eu(SDFR_PIXEL_WAVES_PER_EU)))
+template <class Scene, class = void>
+struct PixelWavesPerSimd { static constexpr int value = SDFR_PIXEL_WAVES_PER_EU; };
+#ifndef SDFR_PIXEL_WAVES_FIXED // developer builds that sweep SDFR_PIXEL_WAVES_PER_EU override the scenes' own choice
+template <class Scene>
+struct PixelWavesPerSimd<Scene, typename VoidOf<decltype(Scene::waves_per_simd)>::type> { static constexpr int value = Scene::waves_per_simd; };
+#endif
+#define SDFR_PIXEL_KERNEL_ATTRS(Scene) __launch_bounds__(SDFR_PIXEL_BLOCK) __attribute__((amdgpu_waves_per_eu(PixelWavesPerSimd<Scene>::value)))
 
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees

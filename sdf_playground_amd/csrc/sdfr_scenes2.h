@@ -245,6 +245,7 @@ struct SceneCoordinateMaterial
 struct SceneDistortion
 {
 	static const char *name() { return "distortion"; }
+	static constexpr int waves_per_simd = 8; // 4.55 -> 4.40 ms at 4K (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}

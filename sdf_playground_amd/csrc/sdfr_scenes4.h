@@ -10,6 +10,7 @@ struct SceneTree
 {
 	static const char *name() { return "tree"; }
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
+	static constexpr int waves_per_simd = 5; // ~1900 instructions per evaluation: registers over residency (sdfr_pixel_kernel.h); 16.9 -> 15.7 ms at 4K
 	static const char *variables() { return ""; }
 	enum { SU_DRIFT = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
@@ -68,50 +69,119 @@ struct SceneTree
 		*tree = t;
 		*leaves = l;
 	}
-	// voronoi lattice: nearest site (id, vector to it) and the distance to the cell border along dir
-	static SDF_HD void lattice(vec2 uv, vec2 dir, float max_offset, vec2 *id, vec2 *to_site, float *border)
+	// voronoi lattice, first half: the nine candidate sites around uv, the nearest (id, vector to it) and the
+	// distances to the nearest and the second nearest
+	struct Lattice { vec2 sites[9]; vec2 local, best_site; float best, second; };
+	static SDF_HD void lattice_sites(vec2 uv, float max_offset, Lattice &L, vec2 *id, vec2 *to_site)
 	{
 		const vec2 cell = floor(uv);
-		const vec2 local = (uv - cell) - 0.5f;
-		float best = 10.f, edge = 10.f;
-		vec2 best_site = V2(0.f, 0.f);
+		L.local = (uv - cell) - 0.5f;
+		L.best = 10.f;
+		L.second = 10.f;
+		L.best_site = V2(0.f, 0.f);
 		// the reference hashes the nine neighbour sites twice (once per loop); same inputs, same
 		// values: they are kept from the first pass
-		vec2 sites[9];
+		bool shared = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+		// The lanes of a wave are neighbouring pixels at similar depths: mostly they all stand in the same lattice
+		// cell, and then nine lanes hash one site each (two PCG hashes, a sixth of an evaluation done nine times
+		// over otherwise) and pass them round through LDS.  Same expression per site, same bits.
+		{
+			__shared__ float site_share[SDFR_MAX_WAVES_PER_BLOCK][18];
+			const unsigned long long active = __ballot(1);
+			const int cx = __float_as_int(cell.x), cy = __float_as_int(cell.y);
+			const bool differs = cx != __builtin_amdgcn_readfirstlane(cx) || cy != __builtin_amdgcn_readfirstlane(cy);
+			if (__ballot(differs) == 0ull && __popcll(active) >= 9)
+			{
+				float *mine = site_share[threadIdx.x >> 6];
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u));
+				if (rank < 9u)
+				{
+					const uint32_t col = rank / 3u;
+					const vec2 off = V2((float)col - 1.f, (float)(rank - 3u * col) - 1.f);
+					const vec2 site = off + voronoi_site(cell + off) * max_offset;
+					mine[2u * rank] = site.x;
+					mine[2u * rank + 1u] = site.y;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+				for (int k = 0; k < 9; ++k) L.sites[k] = V2(mine[2 * k], mine[2 * k + 1]);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				shared = true;
+			}
+		}
+#endif
+		if (!shared)
+		{
+#pragma unroll
+			for (int x = -1; x < 2; ++x)
+#pragma unroll
+				for (int y = -1; y < 2; ++y)
+				{
+					const vec2 off = V2((float)x, (float)y);
+					L.sites[(x + 1) * 3 + (y + 1)] = off + voronoi_site(cell + off) * max_offset;
+				}
+		}
 #pragma unroll
 		for (int x = -1; x < 2; ++x)
 #pragma unroll
 			for (int y = -1; y < 2; ++y)
 			{
-				const vec2 off = V2((float)x, (float)y);
-				const vec2 site = off + voronoi_site(cell + off) * max_offset;
-				sites[(x + 1) * 3 + (y + 1)] = site;
-				const vec2 v = site - local;
+				const vec2 site = L.sites[(x + 1) * 3 + (y + 1)];
+				const vec2 v = site - L.local;
 				const float len = length(v);
-				if (len < best) { best = len; *id = cell + off; best_site = site; *to_site = v; }
+				L.second = min1(L.second, max1(len, L.best)); // not part of the reference: feeds border_lower_bound
+				if (len < L.best) { L.best = len; *id = cell + V2((float)x, (float)y); L.best_site = site; *to_site = v; }
 			}
+	}
+	// second half: the distance to the border of the nearest site's cell along dir
+	static SDF_HD float lattice_border(const Lattice &L, vec2 dir)
+	{
+		float edge = 10.f;
 #pragma unroll
 		for (int k = 0; k < 9; ++k)
 		{
-			const vec2 mid = (sites[k] + best_site) * 0.5f;
-			const vec2 n = normalize(best_site - mid);
-			const float e = abs1(dot(n, local - mid));
+			const vec2 mid = (L.sites[k] + L.best_site) * 0.5f;
+			const vec2 n = normalize(L.best_site - mid);
+			const float e = abs1(dot(n, L.local - mid));
 			edge = min1(edge, e / max1(dot(n, -dir), 0.0001f));
 		}
-		*border = edge;
+		return edge;
 	}
-	// slide for `slide_time`, then hop for `jump_time`: (progress along the slide, hop height)
-	static SDF_HD vec2 hop(float slide_time, float jump_time, float t)
+	// A lower bound of lattice_border() from the first half alone.  Candidate k contributes e_k / den_k with
+	// e_k the distance from `local` to the bisector of (nearest site, site k) and den_k <= |n||dir| <= 1 + 4e-7.
+	// With a = |local - nearest|, b = |local - site k| and D = |nearest - site k| <= a + b (triangle), the
+	// bisector is (b^2 - a^2) / 2D >= (b - a) / 2 away, and b >= the second smallest length.  The sites differ
+	// by >= 0.4 (unit lattice, offsets <= 0.3), all operands are <= 2, so rounding moves the computed e_k, the
+	// lengths and den_k by a few 1e-7: (second - best) / 2, shrunk by 1e-5 relative and 2e-5 absolute, stays
+	// below every computed quotient; the candidate that is the nearest site itself gives 0 / 0 = NaN, which
+	// min() drops, and the initial 10 is above any bound (lengths < 2.2).  NaN in, NaN out: the caller then
+	// evaluates the border.  Checked numerically in tests/test_scene_bounds_cpu.py.
+	static SDF_HD float border_lower_bound(const Lattice &L) { return max1((L.second - L.best) * 0.499995f - 2e-5f, 0.f); }
+	// slide for 10 s, then hop for 1 s: (progress along the slide, hop height).  The reference's hop(10, 1, t)
+	// with its divisions by the constants 11 and 10 as div_c (exact: tests/test_gpu_math.py, SCENE_DIVISORS)
+	static SDF_HD vec2 hop(float t)
 	{
+		const float slide_time = 10.f, jump_time = 1.f;
 		const float total = slide_time + jump_time;
-		const float cycle = t - floor1(t / total) * total;
-		if (cycle < slide_time) return V2(cycle / slide_time, 0.f);
+		const float cycle = t - floor1(div_c(t, total, 1.0f / total)) * total;
+		if (cycle < slide_time) return V2(div_c(cycle, slide_time, 1.0f / slide_time), 0.f);
 		const float j = (cycle - slide_time) / jump_time;
 		return V2(1.f - j, 4.f * (j - j * j));
 	}
 
 	struct Objects { float bounding, tree, leaves, eye, pupil, noise; };
-	static SDF_HD Objects eval_objects(const FrameU &U, vec3 p, vec2 dir2, float bounding)
+	// `others`: what dist() takes the minimum with besides the objects (the ground), or a negative number when
+	// the caller does not look at distances above SDFR_DIST_EPS at all (material()).  The reference clamps tree
+	// and leaves to guard = border * spacing + 0.1 so that no step leaves the lattice cell; border >= 0, so
+	// guard >= 0.1, and guard is monotone in border.  Where the guard's lower bound is not below the minimum of
+	// everything else, the clamp cannot change the scene distance (nor any on_surface() test, 0.1 > SDFR_DIST_EPS)
+	// and the second half of the lattice -- nine normalisations and divisions, a quarter of an evaluation -- is
+	// left out: near a tree, i.e. for the steps that close in on a hit, its six gradient probes and material().
+	static SDF_HD Objects eval_objects(const FrameU &U, vec3 p, vec2 dir2, float bounding, float others)
 	{
 		Objects o;
 		o.bounding = bounding;
@@ -126,11 +196,12 @@ struct SceneTree
 			pos.z = pos.z - U.su[SU_DRIFT];
 			const float spacing = 2.2f;
 			vec2 id = V2(0.f, 0.f), cell_pos = V2(0.f, 0.f);
-			float border;
-			lattice(V2(pos.x, pos.z) / spacing, dir2, 0.3f, &id, &cell_pos, &border);
+			Lattice L;
+			lattice_sites(V2(div_c(pos.x, spacing, 1.0f / spacing), div_c(pos.z, spacing, 1.0f / spacing)), 0.3f, L, &id, &cell_pos);
 			o.noise = sin1(id.x * 356.12f + id.y + 82.6f) * 0.5f + 0.5f;
 
-			const vec2 jump = hop(10.f, 1.f, U.stime + o.noise * 10.f) / spacing;
+			const vec2 hopped = hop(U.stime + o.noise * 10.f);
+			const vec2 jump = V2(div_c(hopped.x, spacing, 1.0f / spacing), div_c(hopped.y, spacing, 1.0f / spacing));
 			cell_pos.y = cell_pos.y - (jump.x * 0.4f - 0.05f);
 			const vec2 cs = cell_pos * spacing;
 			vec3 tree_pos = V3(cs.x, pos.y - jump.y, cs.y);
@@ -140,28 +211,33 @@ struct SceneTree
 			o.eye = sd_sphere(tree_pos - V3(0.2f, 1.f, -0.5f), 0.12f);
 			o.pupil = sd_sphere(tree_pos - V3(0.2f, 1.f, -0.59f), 0.05f);
 			// never step past the border of the current lattice cell
-			const float guard = border * spacing + 0.1f;
-			o.tree = min1(o.tree, guard);
-			o.leaves = min1(o.leaves, guard);
+			const float nearest = min1(min1(min1(o.tree, o.leaves), min1(o.eye, o.pupil)), others);
+			if (!(border_lower_bound(L) * spacing + 0.1f >= nearest))
+			{
+				const float guard = lattice_border(L, dir2) * spacing + 0.1f;
+				o.tree = min1(o.tree, guard);
+				o.leaves = min1(o.leaves, guard);
+			}
 		}
 		return o;
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		const float bounding = ground_dist(p - V3(0.f, 2.f, 0.f), fast, R.ground);
-		const Objects o = eval_objects(U, p, R.dir2, bounding);
+		const float ground = ground_dist(p, fast, R.ground);
+		const Objects o = eval_objects(U, p, R.dir2, bounding, ground);
 		float d = 3e38f;
 		if (bounding >= 0.1f) d = min1(d, bounding);
 		d = min1(d, o.tree);
 		d = min1(d, o.leaves);
 		d = min1(d, o.eye);
 		d = min1(d, o.pupil);
-		return min1(d, ground_dist(p, fast, R.ground));
+		return min1(d, ground);
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
 		const float bounding = dot(sp.pos - V3(0.f, 2.f, 0.f), V3(0.f, 1.f, 0.f));
-		const Objects o = eval_objects(U, sp.pos, normalize(V2(sp.dir.x, sp.dir.z)), bounding);
+		const Objects o = eval_objects(U, sp.pos, V2(0.f, 0.f), bounding, -1.f);
 		if (on_surface(o.tree))
 		{
 			m.diffuse.x = 0.5f;

@@ -261,6 +261,41 @@ extern "C" long long hostsim_check_terrain_octave_skip(long long n, unsigned see
 	return bad;
 }
 
+// the tree scene's lattice (sdfr_scenes4.h): border_lower_bound() never exceeds lattice_border(), whatever the
+// position (small, large, on cell borders) and the direction (unit, axis-parallel, degenerate)
+extern "C" long long hostsim_check_tree_border_bound(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 4242ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	for (long long i = 0; i < n; ++i)
+	{
+		const float span = (i % 4 == 0) ? 3.f : ((i % 4 == 1) ? 60.f : ((i % 4 == 2) ? 5000.f : 3e6f));
+		vec2 uv = V2((rnd() * 2.f - 1.f) * span, (rnd() * 2.f - 1.f) * span);
+		if (i % 16 == 5) uv.x = floor1(uv.x);                 // on a cell wall
+		if (i % 16 == 6) uv = floor(uv) + V2(0.5f, 0.5f);     // cell centre
+		const float a = rnd() * 6.2831853f;
+		vec2 dir = V2(cosf(a), sinf(a));
+		if (i % 32 == 7) dir = V2(1.f, 0.f);
+		if (i % 32 == 8) dir = V2(0.f, 0.f) / 0.f;            // NaN: a vertical ray's normalize(0, 0)
+		SceneTree::Lattice L;
+		vec2 id, to_site;
+		SceneTree::lattice_sites(uv, 0.3f, L, &id, &to_site);
+		const float lb = SceneTree::border_lower_bound(L);
+		const float border = SceneTree::lattice_border(L, dir);
+		if (!(lb <= border) || !(lb >= 0.f) || !(border >= 0.f)) ++bad;
+		// guard = border * 2.2 + 0.1 is monotone, so the bound carries over
+		if (!(lb * 2.2f + 0.1f <= border * 2.2f + 0.1f)) ++bad;
+		if ((double)border - (double)lb < slack) slack = (double)border - (double)lb;
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
 // ---- analysis: what every ray of every pixel of a sample of 8x8 tiles cost (tools/lane_model.py) ---------------
 // A store that behaves like LocalRayStore and writes down, per marched ray, its march iterations, how it ended and
 // its kind.  record: evals (march iterations incl. the final one) | status << 16 | shadow << 20 | depth << 24

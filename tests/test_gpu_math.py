@@ -23,6 +23,7 @@ _scale = np.float32(1.0)
 for _i in range(8):
     _scale = np.float32(_scale / np.float32(1.4))
     SCENE_DIVISORS.append(float(_scale))
+SCENE_DIVISORS += [float(np.float32(2.2)), 11.0]                  # tree: lattice spacing, hop period (10 is in the list already)
 SCENE_DIVISORS += [float(3 ** i) for i in range(2, 8)]   # fractal: level scales 9 .. 2187 (3 is in the list already)
 
 

@@ -152,3 +152,25 @@ def test_terrain_octave_skip_is_invisible(oracle):
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at, levels)
             assert np.array_equal(st, rst)
 
+
+
+def test_tree_border_skip_is_invisible(oracle):
+    """the tree scene leaves the second half of its voronoi lattice out where a lower bound of the cell guard is not below the
+    nearest object: the bound holds, and frames from inside, above and beside the forest keep their bits"""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_tree_border_bound.restype = ctypes.c_longlong
+    L.hostsim_check_tree_border_bound.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_tree_border_bound(3000000, 23, ctypes.byref(slack)) == 0
+    assert slack.value >= 0.0
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    views = [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0), 0.0), ((0.3, 1.2, 0.4), (2.0, 1.0, 3.0), 3.7), ((4.0, 0.4, 1.0), (0.0, 0.8, 0.0), 10.4),
+             ((1.0, 9.0, 1.0), (1.2, 0.0, 1.1), 21.0), ((0.0, 1.9, 0.0), (10.0, 1.7, 4.0), 0.5), ((500.0, 1.5, -300.0), (510.0, 1.0, -290.0), 6.0)]
+    for eye, at, stime in views:
+        f = oracle.default_frame("tree", 72, 48, basis=oracle.camera_lookat(eye, at, fovy, np.float32(72.0 / 48.0)), stime=stime)
+        ref, rst, _ = oracle.render("tree", f, stats=True)
+        img, st = hostsim.render("tree", hostsim.frame_from_oracle(f))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+        assert np.array_equal(st, rst)

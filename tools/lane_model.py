@@ -33,10 +33,19 @@ def main():
     ap.add_argument("--config", default="3")
     ap.add_argument("--frame", type=int, default=5)
     ap.add_argument("--step", type=int, default=4, help="every step-th tile in x and y")
+    ap.add_argument("--scene", default=None, help="instead of a configuration: this scene as tools/scene_table.py renders it (default camera, 3840x2160, 256 steps)")
     a = ap.parse_args()
-    cfg = bench.CONFIGS[a.config]
-    W, H = cfg["width"], cfg["height"]
-    f = hostsim.frame_from_oracle(bench.oracle_frame(po, a.frame, W, H, a.config))
+    if a.scene:
+        cfg = {"scene": a.scene}
+        W, H = 3840, 2160
+        of = po.default_frame(a.scene, W, H, stime=a.frame / 60.0)
+        of.iter_count = 256
+        f = hostsim.frame_from_oracle(of)
+        a.config = a.scene
+    else:
+        cfg = bench.CONFIGS[a.config]
+        W, H = cfg["width"], cfg["height"]
+        f = hostsim.frame_from_oracle(bench.oracle_frame(po, a.frame, W, H, a.config))
     L = hostsim.lib()
     L.hostsim_trace_tiles.restype = ctypes.c_longlong
     L.hostsim_trace_tiles.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
