@@ -37,7 +37,7 @@ hipError_t launch_assemble_strips(int width, int height, int world, const void *
 
 // HDR::process: scene16/bloom1 RGBA16F, ldr8 RGBA8, all device pointers of width*height pixels
 // mid_event (optional) is recorded between the two kernels
-// flags: postprocess_flag_bytes(width, height) bytes of device scratch (one per 128 pixels of a row: lit or not)
+// flags: postprocess_flag_bytes(width, height) bytes of device scratch (one per 32 pixels of a row: lit or not)
 size_t postprocess_flag_bytes(int width, int height);
 hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, unsigned char *flags, hipStream_t stream,
 	hipEvent_t mid_event = nullptr);

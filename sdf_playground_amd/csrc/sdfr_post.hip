@@ -4,7 +4,7 @@
 // 33-tap stride-2 horizontal Gaussian (Engine/shader/bloom.hlsl:14-27), 33-tap stride-2
 // vertical Gaussian (:29-38), exponential tone map blended by the alpha flag
 // (Engine/shader/pshader_hdr.hlsl:16-26) into an R8G8B8A8_UNORM image.  The reference runs
-// three passes over three RGBA16F textures; here two HBM-bound kernels:
+// three passes over three RGBA16F textures; here two kernels:
 //   k_bloom_h        scene(f16) -> bloom1(f16).  The bright-pass is applied once per input
 //                    texel while staging a row segment in LDS (the reference recomputes it
 //                    for each of the 33 taps).
@@ -98,11 +98,11 @@ __device__ __forceinline__ vec4 unpack_half4(uint32_t lo, uint32_t hi)
 // the row is 16-byte aligned).  The taps are two texels apart, so an output pixel only ever reads texels of
 // its own parity: even and odd texels are staged in separate arrays and a wave's 64 tap reads are 64
 // consecutive float4 (no bank conflict).  A wave runs its taps only if one of the 64-texel chunks its
-// windows reach into holds light.  flags[y * n + x / POST_FLAG_PIXELS] (one byte per wave: 128 pixels of a row)
+// windows reach into holds light.  flags[y * n + x / POST_FLAG_PIXELS] (one byte per 32 pixels of a row: the width of a tile of pass 2)
 // says whether anything but zeros was stored there: the vertical pass reads it instead of the bloom texels
 // wherever it is clear.
 #define POST_CHUNKS ((POST_SEG + 2 * POST_HALO) / 64)
-#define POST_FLAG_PIXELS 128
+#define POST_FLAG_PIXELS 32
 __global__ __launch_bounds__(POST_SEG / 2) void k_bloom_h(const uint2 *__restrict__ scene, uint2 *__restrict__ bloom1, unsigned char *__restrict__ flags,
 	int width, int height)
 {
@@ -154,8 +154,14 @@ __global__ __launch_bounds__(POST_SEG / 2) void k_bloom_h(const uint2 *__restric
 	}
 	// a sum of non-zero terms may still round to zero halves: the flag describes what was STORED
 	const bool mine = wave_lit && ((x < width && ((p0.x | p0.y) & 0x7fff7fffu) != 0u) || (x + 1 < width && ((p1.x | p1.y) & 0x7fff7fffu) != 0u));
+	// 16 lanes = 32 pixels = one flag; a wave stores its four flags as one word
 	const unsigned long long stored = __ballot(mine);
-	if ((threadIdx.x & 63) == 0) flags[(size_t)y * (gridDim.x * (POST_SEG / POST_FLAG_PIXELS)) + blockIdx.x * (POST_SEG / POST_FLAG_PIXELS) + w] = stored ? 1 : 0;
+	if ((threadIdx.x & 63) == 0)
+	{
+		const uint32_t four = ((stored & 0xffffull) ? 1u : 0u) | ((stored & 0xffff0000ull) ? 0x100u : 0u) | ((stored & 0xffff00000000ull) ? 0x10000u : 0u) |
+			((stored & 0xffff000000000000ull) ? 0x1000000u : 0u);
+		*reinterpret_cast<uint32_t *>(flags + (size_t)y * (gridDim.x * (POST_SEG / POST_FLAG_PIXELS)) + blockIdx.x * (POST_SEG / POST_FLAG_PIXELS) + 4 * w) = four;
+	}
 }
 
 // ---- pass 2: vertical blur + tone map ---------------------------------------------------------------
@@ -165,45 +171,97 @@ __global__ __launch_bounds__(POST_SEG / 2) void k_bloom_h(const uint2 *__restric
 // [0.5, 255.5] and is never NaN, so the plain conversion (v_cvt_i32_f32: truncation) is all ftoi needs here.
 __device__ __forceinline__ uint32_t to_unorm8(float v) { return (uint32_t)(int)(sat1(v) * 255.f + 0.5f); }
 __device__ __forceinline__ float exp_d3d(float x) { return exp21(x * 1.44269504088896340736f); }
-// pshader_hdr.hlsl:16-26 for one pixel: scene + bloom -> R8G8B8A8_UNORM
+// exp21 for -126 <= y <= 0, where its guards (NaN, overflow, underflow, the 2^128 step) do nothing: the same
+// operations in the same order, 13 instructions instead of 24 and no branches
+__device__ __forceinline__ bool exp2_plain_range(float y) { return (y >= -126.f) & (y <= 0.f); } // NaN: false
+__device__ __forceinline__ float exp2_plain(float y)
+{
+	const float k = rne1(y);
+	const float f = y - k;
+	float p = 1.535336188319500e-4f;
+	p = fma1(p, f, 1.339887440266574e-3f);
+	p = fma1(p, f, 9.618437357674640e-3f);
+	p = fma1(p, f, 5.550332471162809e-2f);
+	p = fma1(p, f, 2.402264791363012e-1f);
+	p = fma1(p, f, 6.931472028550421e-1f);
+	const float res = fma1(p, f, 1.0f);
+	return res * bits_f32((uint32_t)((int)k + 127) << 23);
+}
+// one channel of pshader_hdr.hlsl:16-26 from its exponential on
+__device__ __forceinline__ uint32_t tone_channel(float sc, float exponential, float a) { return to_unorm8(lerp1(sc, 1.f - exponential, a)); }
+// pshader_hdr.hlsl:16-26 for one pixel: scene + bloom -> R8G8B8A8_UNORM.
+//  * DARK: the caller knows bloom is +0 in all four channels.  scene + +0 differs from scene only for scene = -0
+//    (the sum is +0), and the exponential of either zero is 1: the addition is left out.
+//  * The exponentials: almost every texel has all four arguments in [-126, 0] (colours are not negative and below
+//    87); if that holds for every lane of the wave, the guard-free form runs, else exp21 for all.
+//  * Alpha: the renderer writes 0 or 1 there (|hdr flag|, sdfr_render_pixel.h), and without bloom on the alpha
+//    channel the output byte is then a constant (0 -> 0; 1 -> the byte of lerp(1, 1 - exp(-1), 1)): if that holds for
+//    every lane, the fourth exponential, blend and conversion are not computed.  Any other alpha takes the formula.
+template <bool DARK>
 __device__ __forceinline__ uint32_t tone_map(vec4 sc, vec4 bloom)
 {
-	const vec4 total = sc + bloom;
-	const vec4 e = -total * 1.f; // exposure 1
-	const vec4 l = 1.f - V4(exp_d3d(e.x), exp_d3d(e.y), exp_d3d(e.z), exp_d3d(e.w));
+	const vec4 total = DARK ? sc : sc + bloom;
+	const vec4 y = (-total * 1.f) * 1.44269504088896340736f; // exposure 1; exp(x) = exp2(x * log2(e)) as D3D compiles it
 	const float a = sc.w;
-	const vec4 o = V4(lerp1(sc.x, l.x, a), lerp1(sc.y, l.y, a), lerp1(sc.z, l.z, a), lerp1(sc.w, l.w, a));
-	return to_unorm8(o.x) | (to_unorm8(o.y) << 8) | (to_unorm8(o.z) << 16) | (to_unorm8(o.w) << 24);
+	const bool flag_alpha = (DARK | (bloom.w == 0.f)) & ((sc.w == 0.f) | (sc.w == 1.f));
+	uint32_t out;
+	if (__all(exp2_plain_range(y.x) & exp2_plain_range(y.y) & exp2_plain_range(y.z) & (flag_alpha | exp2_plain_range(y.w))))
+		out = tone_channel(sc.x, exp2_plain(y.x), a) | (tone_channel(sc.y, exp2_plain(y.y), a) << 8) | (tone_channel(sc.z, exp2_plain(y.z), a) << 16);
+	else
+		out = tone_channel(sc.x, exp21(y.x), a) | (tone_channel(sc.y, exp21(y.y), a) << 8) | (tone_channel(sc.z, exp21(y.z), a) << 16);
+	if (__all(flag_alpha))
+	{
+		const uint32_t one = tone_channel(1.f, exp2_plain((-1.f * 1.f) * 1.44269504088896340736f), 1.f); // folds to a constant
+		out |= (sc.w == 1.f ? one : 0u) << 24;
+	}
+	else
+		out |= tone_channel(sc.w, exp21(y.w), a) << 24;
+	return out;
 }
 
+// One block per 32 x 32 tile.  Tried and dropped: tone-mapping the dark tiles in a kernel of their own (no LDS, hence
+// full residency: a black 4K frame in 24 instead of 31 us) and handing the lit ones to resident blocks through lists --
+// the list-driven blocks needed 1.5x as long per lit tile as one block per tile does (dense frame 240 against 150 us,
+// cube_sea 76 against 58 us), whatever the grid, the hand-out (strided, atomic cursor) or the tile-to-XCD mapping.
 __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ scene, const uint2 *__restrict__ bloom1,
 	const unsigned char *__restrict__ flags, int flags_per_row, uint32_t *__restrict__ ldr, int width, int height)
 {
 	__shared__ float4 tile[POST_TY + 2 * POST_HALO][POST_TX];
+	__shared__ uint32_t rows_lit[3]; // which of the 96 staged rows hold light: bit r of rows_lit[r / 32]
 	const int x0 = blockIdx.x * POST_TX, y0 = blockIdx.y * POST_TY;
-	// Is any of the 96 rows of bloom texels this tile blurs over lit?  (A 32-pixel tile lies inside one flag's 128 pixels.)
+	// A dark tile (below) only tone-maps: a thread takes four neighbouring pixels of a row (32-byte loads, 16-byte
+	// stores).  Their loads are issued before the flags are looked at, so that the two round trips overlap; a lit
+	// tile drops them (it is the rarer case and reads its scene texels in another arrangement).
+	const int dr = threadIdx.x >> 3, dy = y0 + dr, dx = x0 + (threadIdx.x & 7) * 4;
+	const size_t at = (size_t)dy * width + dx;
+	const bool mine = dy < height && dx < width;
+	const bool wide = mine && dx + 3 < width && (at & 1) == 0; // 16-byte aligned: two texels per load
+	uint4 s01 = make_uint4(0u, 0u, 0u, 0u), s23 = s01;
+	if (wide)
+	{
+		s01 = *reinterpret_cast<const uint4 *>(scene + at);
+		s23 = *reinterpret_cast<const uint4 *>(scene + at + 2);
+	}
+	// Is any of the 96 rows of bloom texels this tile blurs over lit?  (A tile is as wide as a flag.)
 	int row_lit = 0;
 	if (threadIdx.x < POST_TY + 2 * POST_HALO)
 	{
 		const int y = y0 - POST_HALO + (int)threadIdx.x;
 		if (y >= 0 && y < height) row_lit = flags[(size_t)y * flags_per_row + x0 / POST_FLAG_PIXELS];
 	}
+	if (threadIdx.x < 3) rows_lit[threadIdx.x] = 0u;
 	if (!__syncthreads_or(row_lit))
 	{
-		// Dark tile: the blur is +0 everywhere, bloom2 = f16(+0 * 2) = +0; only the tone map is left.  No bloom
-		// texel is read; a thread takes four neighbouring pixels of a row (32-byte loads, 16-byte stores).
-		const int r = threadIdx.x >> 3, y = y0 + r, x = x0 + (threadIdx.x & 7) * 4;
-		if (y >= height || x >= width) return;
+		// Dark tile: the blur is +0 everywhere, bloom2 = f16(+0 * 2) = +0; only the tone map is left.  No bloom texel is read.
+		if (!mine) return;
 		const vec4 dark = through_half4(V4(0.f, 0.f, 0.f, 0.f) * 2.f);
-		const size_t at = (size_t)y * width + x;
-		if (x + 3 < width && (at & 1) == 0) // 16-byte aligned: two texels per load
+		if (wide)
 		{
-			const uint4 s01 = *reinterpret_cast<const uint4 *>(scene + at), s23 = *reinterpret_cast<const uint4 *>(scene + at + 2);
 			uint4 o;
-			o.x = tone_map(unpack_half4(s01.x, s01.y), dark);
-			o.y = tone_map(unpack_half4(s01.z, s01.w), dark);
-			o.z = tone_map(unpack_half4(s23.x, s23.y), dark);
-			o.w = tone_map(unpack_half4(s23.z, s23.w), dark);
+			o.x = tone_map<true>(unpack_half4(s01.x, s01.y), dark);
+			o.y = tone_map<true>(unpack_half4(s01.z, s01.w), dark);
+			o.z = tone_map<true>(unpack_half4(s23.x, s23.y), dark);
+			o.w = tone_map<true>(unpack_half4(s23.z, s23.w), dark);
 			if ((at & 3) == 0)
 				*reinterpret_cast<uint4 *>(ldr + at) = o;
 			else
@@ -213,34 +271,40 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 		}
 		else
 		{
-			for (int k = 0; k < 4 && x + k < width; ++k) ldr[at + k] = tone_map(load_half4(scene, at + k), dark);
+			for (int k = 0; k < 4 && dx + k < width; ++k) ldr[at + k] = tone_map<true>(load_half4(scene, at + k), dark);
 		}
 		return;
 	}
 	const int tx = threadIdx.x & (POST_TX - 1), ty = threadIdx.x / POST_TX; // 32 x 8
 	const int x = x0 + tx;
-	int lit = 0;
 	for (int r = ty; r < POST_TY + 2 * POST_HALO; r += 8)
 	{
 		const int y = y0 - POST_HALO + r;
 		vec4 c = V4(0.f, 0.f, 0.f, 0.f);
 		if (x < width && y >= 0 && y < height) c = load_half4(bloom1, (size_t)y * width + x);
-		lit |= is_lit(c);
 		tile[r][tx] = make_float4(c.x, c.y, c.z, c.w);
+		// a wave stages two rows (lanes 0-31: row r, lanes 32-63: row r + 1, r even)
+		const unsigned long long lit = __ballot(is_lit(c));
+		if ((threadIdx.x & 63) == 0 && lit)
+			atomicOr(&rows_lit[r >> 5], (((uint32_t)lit ? 1u : 0u) | ((uint32_t)(lit >> 32) ? 2u : 0u)) << (r & 31));
 	}
-	const int block_lit = __syncthreads_or(lit); // the 128 pixels of the flag may be lit elsewhere than in these 32 columns
+	__syncthreads();
 	if (x >= width) return;
+	const unsigned long long low = (unsigned long long)rows_lit[0] | ((unsigned long long)rows_lit[1] << 32);
+	const unsigned long long high = rows_lit[2];
 	for (int r = ty; r < POST_TY; r += 8)
 	{
 		const int y = y0 + r;
 		if (y >= height) break;
 		vec4 sum = V4(0.f, 0.f, 0.f, 0.f);
-		if (block_lit) Taps<-16, 2 * POST_TX>::run(sum, &tile[r + POST_HALO][tx]);
+		// output row r blurs staged rows r .. r + 64: rows r .. 63 of `low` and rows 64 .. 64 + r of `high`; nothing there: a sum of zeros
+		if (((low >> r) | (high & ((2ull << r) - 1ull))) != 0ull) Taps<-16, 2 * POST_TX>::run(sum, &tile[r + POST_HALO][tx]);
 		const vec4 bloom = through_half4(sum * 2.f); // the reference stores bloom2 as f16
-		ldr[(size_t)y * width + x] = tone_map(load_half4(scene, (size_t)y * width + x), bloom);
+		ldr[(size_t)y * width + x] = tone_map<false>(load_half4(scene, (size_t)y * width + x), bloom);
 	}
 }
 
+// the scratch of a frame: one flag per 32 pixels of a row
 size_t postprocess_flag_bytes(int width, int height) { return (size_t)((width + POST_SEG - 1) / POST_SEG) * (POST_SEG / POST_FLAG_PIXELS) * (size_t)height; }
 
 hipError_t launch_postprocess(int width, int height, const void *scene16, void *bloom1, void *ldr8, unsigned char *flags, hipStream_t stream,

@@ -66,6 +66,27 @@ def test_postprocess_mostly_dark_images(renderer, oracle, size):
     _check(renderer, oracle, img)
 
 
+@pytest.mark.parametrize("dark", [True, False])
+def test_postprocess_unusual_texels(renderer, oracle, dark):
+    """what the tone map's short cuts must not change (sdfr_post.hip, tone_map): negative colours, infinities, NaN,
+    colours past the exponential's underflow, alpha that is not the renderer's 0 / 1 flag (fractions, negative, NaN,
+    inf, -0) -- in tiles without any bloom (dark) and in tiles that blur a bright neighbourhood"""
+    w, h = 200, 136
+    rng = np.random.default_rng(77 + dark)
+    img = np.zeros((h, w, 4), np.float16)
+    img[..., :3] = (rng.random((h, w, 3)) * (0.3 if dark else 4.0)).astype(np.float16)
+    img[..., 3] = rng.integers(0, 2, (h, w))
+    specials = [float("inf"), float("-inf"), float("nan"), -0.0, -1.5, -300.0, 88.0, 90.0, 200.0, 65504.0, 6e-8, -6e-8, 0.5, 2.0]
+    for k in range(900):
+        x, y, c = int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(0, 4))
+        img[y, x, c] = specials[int(rng.integers(0, len(specials)))]
+    if dark:  # keep the bright-pass shut: no texel brighter than 0.75 (NaN / inf colours would light the tile)
+        rgb = img[..., :3].astype(np.float32)
+        bad = ~np.isfinite(rgb).all(axis=2) | (rgb.max(axis=2) > 0.7)
+        img[bad, :3] = np.float16(-2.0)
+    _check(renderer, oracle, img)
+
+
 def test_postprocess_of_rendered_frame(renderer, oracle):
     """render (RGBA16F target) -> process, as Application::render does (Application.cpp:274-284)."""
     import torch
