@@ -165,7 +165,11 @@ __global__ __launch_bounds__(POST_SEG / 2) void k_bloom_h(const uint2 *__restric
 }
 
 // ---- pass 2: vertical blur + tone map ---------------------------------------------------------------
-#define POST_TX 32
+#ifndef POST_TX
+#define POST_TX 16
+#endif
+#define POST_ROWS_PER_STEP (256 / POST_TX) // rows the block's 256 threads cover at once
+#define POST_DARK_PIXELS (POST_TX * POST_TY / 256) // neighbouring pixels of a row one thread tone-maps in a dark tile: 2 or 4
 #define POST_TY 32
 // D3D's float -> UNORM8: saturate (NaN -> 0), scale, add a half, truncate.  After sat1 the value lies in
 // [0.5, 255.5] and is never NaN, so the plain conversion (v_cvt_i32_f32: truncation) is all ftoi needs here.
@@ -229,20 +233,20 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 	__shared__ float4 tile[POST_TY + 2 * POST_HALO][POST_TX];
 	__shared__ uint32_t rows_lit[3]; // which of the 96 staged rows hold light: bit r of rows_lit[r / 32]
 	const int x0 = blockIdx.x * POST_TX, y0 = blockIdx.y * POST_TY;
-	// A dark tile (below) only tone-maps: a thread takes four neighbouring pixels of a row (32-byte loads, 16-byte
-	// stores).  Their loads are issued before the flags are looked at, so that the two round trips overlap; a lit
-	// tile drops them (it is the rarer case and reads its scene texels in another arrangement).
-	const int dr = threadIdx.x >> 3, dy = y0 + dr, dx = x0 + (threadIdx.x & 7) * 4;
+	// A dark tile (below) only tone-maps: a thread takes POST_DARK_PIXELS neighbouring pixels of a row (16-byte loads).
+	// Their loads are issued before the flags are looked at, so that the two round trips overlap; a lit tile drops
+	// them (it is the rarer case and reads its scene texels in another arrangement).
+	const int dr = threadIdx.x >> 3, dy = y0 + dr, dx = x0 + (threadIdx.x & 7) * POST_DARK_PIXELS;
 	const size_t at = (size_t)dy * width + dx;
 	const bool mine = dy < height && dx < width;
-	const bool wide = mine && dx + 3 < width && (at & 1) == 0; // 16-byte aligned: two texels per load
+	const bool wide = mine && dx + POST_DARK_PIXELS - 1 < width && (at & 1) == 0; // 16-byte aligned: two texels per load
 	uint4 s01 = make_uint4(0u, 0u, 0u, 0u), s23 = s01;
 	if (wide)
 	{
 		s01 = *reinterpret_cast<const uint4 *>(scene + at);
-		s23 = *reinterpret_cast<const uint4 *>(scene + at + 2);
+		if (POST_DARK_PIXELS == 4) s23 = *reinterpret_cast<const uint4 *>(scene + at + 2);
 	}
-	// Is any of the 96 rows of bloom texels this tile blurs over lit?  (A tile is as wide as a flag.)
+	// Is any of the 96 rows of bloom texels this tile blurs over lit?  (A tile is no wider than a flag.)
 	int row_lit = 0;
 	if (threadIdx.x < POST_TY + 2 * POST_HALO)
 	{
@@ -260,39 +264,48 @@ __global__ __launch_bounds__(256) void k_bloom_v_tone(const uint2 *__restrict__ 
 			uint4 o;
 			o.x = tone_map<true>(unpack_half4(s01.x, s01.y), dark);
 			o.y = tone_map<true>(unpack_half4(s01.z, s01.w), dark);
-			o.z = tone_map<true>(unpack_half4(s23.x, s23.y), dark);
-			o.w = tone_map<true>(unpack_half4(s23.z, s23.w), dark);
-			if ((at & 3) == 0)
-				*reinterpret_cast<uint4 *>(ldr + at) = o;
-			else
+			if (POST_DARK_PIXELS == 4)
 			{
-				ldr[at] = o.x; ldr[at + 1] = o.y; ldr[at + 2] = o.z; ldr[at + 3] = o.w;
+				o.z = tone_map<true>(unpack_half4(s23.x, s23.y), dark);
+				o.w = tone_map<true>(unpack_half4(s23.z, s23.w), dark);
+				if ((at & 3) == 0)
+					*reinterpret_cast<uint4 *>(ldr + at) = o;
+				else
+				{
+					ldr[at] = o.x; ldr[at + 1] = o.y; ldr[at + 2] = o.z; ldr[at + 3] = o.w;
+				}
 			}
+			else
+				*reinterpret_cast<uint2 *>(ldr + at) = make_uint2(o.x, o.y); // at is even: 8-byte aligned
 		}
 		else
 		{
-			for (int k = 0; k < 4 && dx + k < width; ++k) ldr[at + k] = tone_map<true>(load_half4(scene, at + k), dark);
+			for (int k = 0; k < POST_DARK_PIXELS && dx + k < width; ++k) ldr[at + k] = tone_map<true>(load_half4(scene, at + k), dark);
 		}
 		return;
 	}
-	const int tx = threadIdx.x & (POST_TX - 1), ty = threadIdx.x / POST_TX; // 32 x 8
+	const int tx = threadIdx.x & (POST_TX - 1), ty = threadIdx.x / POST_TX;
 	const int x = x0 + tx;
-	for (int r = ty; r < POST_TY + 2 * POST_HALO; r += 8)
+	for (int r = ty; r < POST_TY + 2 * POST_HALO; r += POST_ROWS_PER_STEP)
 	{
 		const int y = y0 - POST_HALO + r;
 		vec4 c = V4(0.f, 0.f, 0.f, 0.f);
 		if (x < width && y >= 0 && y < height) c = load_half4(bloom1, (size_t)y * width + x);
 		tile[r][tx] = make_float4(c.x, c.y, c.z, c.w);
-		// a wave stages two rows (lanes 0-31: row r, lanes 32-63: row r + 1, r even)
+		// a wave stages 64 / POST_TX rows (POST_TX lanes each), the first of them -- lane 0's r -- a multiple of that
 		const unsigned long long lit = __ballot(is_lit(c));
 		if ((threadIdx.x & 63) == 0 && lit)
-			atomicOr(&rows_lit[r >> 5], (((uint32_t)lit ? 1u : 0u) | ((uint32_t)(lit >> 32) ? 2u : 0u)) << (r & 31));
+		{
+			uint32_t rows = 0u;
+			for (int g = 0; g < 64 / POST_TX; ++g) rows |= ((lit >> (g * POST_TX)) & ((1ull << POST_TX) - 1ull)) ? 1u << g : 0u;
+			atomicOr(&rows_lit[r >> 5], rows << (r & 31));
+		}
 	}
 	__syncthreads();
 	if (x >= width) return;
 	const unsigned long long low = (unsigned long long)rows_lit[0] | ((unsigned long long)rows_lit[1] << 32);
 	const unsigned long long high = rows_lit[2];
-	for (int r = ty; r < POST_TY; r += 8)
+	for (int r = ty; r < POST_TY; r += POST_ROWS_PER_STEP)
 	{
 		const int y = y0 + r;
 		if (y >= height) break;
