@@ -36,6 +36,50 @@ enum MaterialId
 
 SDF_HD bool on_surface(float d) { return abs1(d) < SDFR_DIST_EPS; }
 
+// ---- values a whole wave needs alike, computed once --------------------------------------------
+// Scene functions that hash the corners / neighbours of the lattice cell a point lies in do the same n independent
+// computations in every lane whenever the lanes stand in the same cell -- and the lanes of a wave are neighbouring
+// pixels at similar depths, so mostly they do.  WaveShare lets n lanes compute one value each and pass them round
+// through LDS (n <= SDFR_WAVE_SHARE_SLOTS floats per wave): same expression per value, same bits.
+//     uint32_t rank;
+//     if (WaveShare::agree(key.x, key.y, key.z, n, &rank)) {        // wave-uniform: all active lanes hold these bits, >= n lanes active
+//         if (rank < n) WaveShare::slots()[rank] = f(rank);         // the n lowest active lanes
+//         WaveShare::publish();
+//         ... read WaveShare::slots()[0 .. n) ...
+//         WaveShare::release();                                     // before the slots are written again
+//     } else { every lane computes all n itself }
+// Device code only; the host build of a scene (tests/hostsim) takes the else branch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDFR_WAVE_SHARE_SLOTS 24
+struct WaveShare
+{
+	static __device__ __forceinline__ float *slots()
+	{
+		__shared__ float share[SDFR_MAX_WAVES_PER_BLOCK][SDFR_WAVE_SHARE_SLOTS];
+		return share[threadIdx.x >> 6];
+	}
+	static __device__ __forceinline__ bool agree(float a, float b, float c, uint32_t n, uint32_t *rank)
+	{
+		const unsigned long long active = __ballot(1);
+		const int ia = __float_as_int(a), ib = __float_as_int(b), ic = __float_as_int(c);
+		const bool differs = ia != __builtin_amdgcn_readfirstlane(ia) || ib != __builtin_amdgcn_readfirstlane(ib) || ic != __builtin_amdgcn_readfirstlane(ic);
+		*rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u));
+		return __ballot(differs) == 0ull && (uint32_t)__popcll(active) >= n;
+	}
+	static __device__ __forceinline__ void publish()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	static __device__ __forceinline__ void release()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+};
+#endif
+
 // ---- primitives ------------------------------------------------------------------------
 SDF_HD float sd_sphere(vec3 p, float r) { return length(p) - r; }
 

@@ -239,6 +239,28 @@ struct SceneTerrain
 	static SDF_HD float base(vec3 p)
 	{
 		const vec3 cell = floor(p);
+#if defined(__HIP_DEVICE_COMPILE__)
+		// the radii hang on the cell alone (a sine hash per corner: two thirds of base()); where the whole wave stands
+		// in one cell -- the coarse octaves, mostly -- eight lanes work out one radius each (WaveShare, sdfr_lib.h)
+		uint32_t rank;
+		if (WaveShare::agree(cell.x, cell.y, cell.z, 8u, &rank))
+		{
+			float *slots = WaveShare::slots();
+			if (rank < 8u) slots[rank] = lerp1(0.f, 0.3f, lattice_noise(cell + V3((float)(rank >> 2), (float)((rank >> 1) & 1u), (float)(rank & 1u))));
+			WaveShare::publish();
+			float r[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) r[k] = slots[k];
+			WaveShare::release();
+			float nearest = 3e38f;
+			// the same eight values as below, and min() over them in the same grouping
+			float v[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) v[k] = sd_sphere(p - (cell + V3((float)(k >> 2), (float)((k >> 1) & 1), (float)(k & 1))), r[k]);
+			nearest = min1(min1(min1(v[0], v[1]), min1(v[2], v[3])), min1(min1(v[4], v[5]), min1(v[6], v[7])));
+			return nearest;
+		}
+#endif
 		const float a = corner_sphere(cell, p, V3(0.f, 0.f, 0.f)), b = corner_sphere(cell, p, V3(0.f, 0.f, 1.f));
 		const float c = corner_sphere(cell, p, V3(0.f, 1.f, 0.f)), d = corner_sphere(cell, p, V3(0.f, 1.f, 1.f));
 		const float e = corner_sphere(cell, p, V3(1.f, 0.f, 0.f)), f = corner_sphere(cell, p, V3(1.f, 0.f, 1.f));

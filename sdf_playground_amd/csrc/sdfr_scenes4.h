@@ -83,33 +83,25 @@ struct SceneTree
 		// values: they are kept from the first pass
 		bool shared = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-		// The lanes of a wave are neighbouring pixels at similar depths: mostly they all stand in the same lattice
-		// cell, and then nine lanes hash one site each (two PCG hashes, a sixth of an evaluation done nine times
-		// over otherwise) and pass them round through LDS.  Same expression per site, same bits.
+		// mostly every lane of the wave stands in the same lattice cell: then nine lanes hash one site each (two PCG
+		// hashes: a sixth of an evaluation, done nine times over otherwise) and pass them round (WaveShare, sdfr_lib.h)
 		{
-			__shared__ float site_share[SDFR_MAX_WAVES_PER_BLOCK][18];
-			const unsigned long long active = __ballot(1);
-			const int cx = __float_as_int(cell.x), cy = __float_as_int(cell.y);
-			const bool differs = cx != __builtin_amdgcn_readfirstlane(cx) || cy != __builtin_amdgcn_readfirstlane(cy);
-			if (__ballot(differs) == 0ull && __popcll(active) >= 9)
+			uint32_t rank;
+			if (WaveShare::agree(cell.x, cell.y, 0.f, 9u, &rank))
 			{
-				float *mine = site_share[threadIdx.x >> 6];
-				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u));
+				float *slots = WaveShare::slots();
 				if (rank < 9u)
 				{
 					const uint32_t col = rank / 3u;
 					const vec2 off = V2((float)col - 1.f, (float)(rank - 3u * col) - 1.f);
 					const vec2 site = off + voronoi_site(cell + off) * max_offset;
-					mine[2u * rank] = site.x;
-					mine[2u * rank + 1u] = site.y;
+					slots[2u * rank] = site.x;
+					slots[2u * rank + 1u] = site.y;
 				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				WaveShare::publish();
 #pragma unroll
-				for (int k = 0; k < 9; ++k) L.sites[k] = V2(mine[2 * k], mine[2 * k + 1]);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
+				for (int k = 0; k < 9; ++k) L.sites[k] = V2(slots[2 * k], slots[2 * k + 1]);
+				WaveShare::release();
 				shared = true;
 			}
 		}
