@@ -165,6 +165,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
+	static constexpr int waves_per_simd = 6; // 22 instead of 38 spilled registers: configuration 3 1.393 -> 1.371 ms (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -304,6 +305,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
+	static constexpr int waves_per_simd = 8; // configuration 4 1.507 -> 1.490 ms (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -531,6 +533,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
