@@ -131,6 +131,14 @@ SDF_HD float rcp1(float a)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDFR_SAFE_MATH)
 	const float y = __builtin_amdgcn_rcpf(a);
 	const float r = __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
+	// +-0 (0x60) and +-inf (0x204): rcp is exact there.  __builtin_amdgcn_class is the DOUBLE class test (the float goes
+	// through v_cvt_f64_f32): on purpose.  Measured on MI355X (round 2): with the float test (classf: two instructions
+	// and the compiler's s_nops fewer per call) labyrinth 4K takes 1.40 instead of 1.38 ms and distortion 5.15 instead of
+	// 4.45 ms; with a select-free form (min(e, 2^-20) instead of test + select: four instructions in all) 1.42 and 4.84.
+	// Same bits all three (sdfr_selftest_math what = 4), same registers, same spills, no instruction-cache misses
+	// (SQC_ICACHE_MISSES 6e3 of 2.7e8 requests), no effect of the distance between v_rcp and its consumer in a
+	// micro-benchmark (tools/ubench/select_ubench.hip); under rocprofv3 the shorter form issues 0.4 % fewer VALU instructions
+	// and spends 2.4 % more busy cycles (SQ_WAIT_INST_ANY + 7 %).  The cause is not known, the numbers are.
 	return __builtin_amdgcn_class(a, 0x260 | 0x204) ? y : r; // +-0 (0x60) and +-inf (0x204): rcp is exact there
 #else
 	return 1.0f / a;

@@ -31,6 +31,8 @@ def renderer():
     ("labyrinth", "SceneLabyrinth", None, True),
     ("lense", "SceneLense", dict(mixing=0.8, zpos=9.0), True),
     ("light_shadows", "SceneLightShadows", None, False),
+    ("tree", "SceneTree", None, True),        # WaveShare (per-wave LDS inside the scene text), waves_per_simd
+    ("terrain", "SceneTerrain", None, False),
 ])
 def test_built_in_scene_compiled_at_run_time_matches_oracle(renderer, oracle, scene, struct_name, variables, fast_math):
     f = _setup(renderer, oracle, scene, 0.75, variables=variables)

@@ -11,7 +11,7 @@ def test_example_scene_compiles_offline():
     assert ok, log
 
 
-@pytest.mark.parametrize("struct_name", ["SceneFastSphere", "SceneLense"])
+@pytest.mark.parametrize("struct_name", ["SceneFastSphere", "SceneLense", "SceneTree", "SceneTerrain"])  # the last two pass values round the wave through LDS
 def test_built_in_scene_text_compiles_as_run_time_scene(struct_name):
     ok, log = sp.check_scene_source(aot_scene_source(struct_name))
     assert ok, log
