@@ -114,6 +114,8 @@ struct RowMap
 	// order in which the launch's waves take the tile rows: tile row (ty * tile_row_mul + tile_row_add) % tile_rows
 	// is the ty-th to be handed out (an affine permutation: mul coprime to tile_rows; 1, 0 = top to bottom)
 	uint32_t tile_row_mul, tile_row_add;
+	// persistent launches: a wave ends after this many tiles and a fresh one takes its place (0 = never); set by the launcher
+	uint32_t retire_after;
 };
 
 // local strip index of this launch -> strip index in the frame

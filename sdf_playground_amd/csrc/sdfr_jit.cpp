@@ -206,10 +206,10 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	(void)hipGetDevice(&device);
 	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, false); // a run-time scene: one wave per tile unless asked otherwise
 	if (mode.blocks_per_cu > 0 && mode.blocks_per_cu < per_cu) per_cu = mode.blocks_per_cu;
-	uint32_t blocks = (uint32_t)(device_cu_count(device) * per_cu);
-	if (blocks > (n_work + bt - 1u) / bt || !mode.persistent) blocks = (n_work + bt - 1u) / bt;
+	const uint32_t blocks = pixel_launch_blocks(mode, (n_work + bt - 1u) / bt, (uint32_t)(device_cu_count(device) * per_cu));
 	FrameU frame = U;
 	RowMap rows = rm;
+	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
 	float *queue = ws.ray_queue;
 	size_t cap = ws.capacity;
 	RenderTotals *partials = ws.partials;

@@ -53,8 +53,19 @@ int pixel_tile_cursor_words();
 // how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per
 // tile.  launch_mode: 0 = the scene's own default (PersistentTiles), 1 = one wave per tile, 2 = persistent;
 // the developer knobs SDFR_PIXEL_PERSISTENT=0|1 and SDFR_PIXEL_BLOCKS_PER_CU=n (cap of a persistent grid) override.
-struct PixelLaunchMode { bool persistent; int blocks_per_cu; };
-PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent);
+// retire_after (persistent launches; SDFR_PIXEL_RETIRE_AFTER=n overrides, 0 = never): see pixel_launch_blocks.
+struct PixelLaunchMode { bool persistent; int blocks_per_cu; int retire_after; };
+PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent, int scene_retire_after = 8);
+// Blocks of a pixel launch.  One wave per tile: as many as tiles.  Persistent: what stays resident -- and, when waves
+// retire after `retire_after` tiles, the replacements as well: tiles / retire_after, plus half a chip of waves that
+// end for want of tiles before they have had their share.  Why waves retire: a SIMD serves its oldest waves first, so
+// of the waves that start together the ones in its upper slots crawl for the whole frame (tools/wave_trace.py: two
+// tiles against sixty), and what they hold when the queue runs dry is finished by one or two waves per SIMD while the
+// rest of the chip idles -- the last 7 % of a labyrinth frame, a fifth of a fractal frame.  A wave that leaves after 8
+// tiles is replaced by a younger one, the crawlers become the oldest and catch up.  Measured (ms per frame, one frame
+// in flight; never / 4 / 8 / 16): labyrinth 4K 1.375 / 1.370 / 1.359 / 1.366, cube_sea 1080p 0.883 / 0.844 / 0.840 /
+// 0.877, fractal 4K 1.607 / 1.470 / 1.485 / 1.549 (one wave per tile: 1.397, -, 1.482).
+uint32_t pixel_launch_blocks(const PixelLaunchMode &mode, uint32_t tiles, uint32_t resident_blocks);
 
 int pixel_block_threads(); // block size of the pixel kernels (partials are sized by it)
 int device_cu_count(int device);

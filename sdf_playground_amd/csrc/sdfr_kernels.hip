@@ -86,7 +86,7 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 }
 int pixel_tile_cursor_words() { return SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE; }
 
-PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent)
+PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent, int scene_retire_after)
 {
 	static const int env_persistent = [] { const char *e = getenv("SDFR_PIXEL_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
 	static const int env_blocks = [] { const char *e = getenv("SDFR_PIXEL_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
@@ -94,7 +94,18 @@ PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent
 	m.persistent = launch_mode == 2 || (launch_mode == 0 && scene_default_persistent);
 	if (env_persistent >= 0) m.persistent = env_persistent != 0;
 	m.blocks_per_cu = env_blocks;
+	static const int env_retire = [] { const char *e = getenv("SDFR_PIXEL_RETIRE_AFTER"); return e ? atoi(e) : -1; }();
+	m.retire_after = env_retire >= 0 ? env_retire : scene_retire_after;
 	return m;
+}
+
+uint32_t pixel_launch_blocks(const PixelLaunchMode &mode, uint32_t tiles, uint32_t resident_blocks)
+{
+	if (!mode.persistent) return tiles;
+	uint32_t blocks = resident_blocks;
+	if (mode.retire_after > 0) blocks = resident_blocks / 2u + tiles / (uint32_t)mode.retire_after;
+	if (blocks < resident_blocks) blocks = resident_blocks;
+	return blocks < tiles ? blocks : tiles;
 }
 
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors)

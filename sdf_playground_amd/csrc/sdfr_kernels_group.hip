@@ -287,12 +287,13 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	int device = 0;
 	(void)hipGetDevice(&device);
 	const uint32_t tiles_blocks = (n_work + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK;
-	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, PersistentTiles<Scene>::value);
+	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, PersistentTiles<Scene>::value, RetireAfter<Scene>::value);
 	uint32_t per_cu = (uint32_t)blocks_per_cu;
 	if (mode.blocks_per_cu > 0 && (uint32_t)mode.blocks_per_cu < per_cu) per_cu = (uint32_t)mode.blocks_per_cu;
-	uint32_t blocks = (uint32_t)device_cu_count(device) * per_cu;
-	if (blocks > tiles_blocks || !mode.persistent) blocks = tiles_blocks;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rm, n_work, out, format, pixel_stats, ws.partials, totals,
+	const uint32_t blocks = pixel_launch_blocks(mode, tiles_blocks, (uint32_t)device_cu_count(device) * per_cu);
+	RowMap rows = rm;
+	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rows, n_work, out, format, pixel_stats, ws.partials, totals,
 		ws.ray_queue, ws.capacity, mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr);
 	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors);
 }

@@ -338,6 +338,7 @@ struct TileQueue
 		shard = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (SDFR_TILE_CURSORS - 1); // HW_REG_XCC_ID
 	}
 	__device__ __forceinline__ uint32_t tiles_of(uint32_t s) const { return s < n_tiles ? (n_tiles - s + SDFR_TILE_CURSORS - 1u) / SDFR_TILE_CURSORS : 0u; }
+	__device__ __forceinline__ bool holds_claimed_tiles() const { return next_k < end_k; }
 	// how long the last tile took decides how many tiles the next atomic claims
 	__device__ __forceinline__ void tile_took(uint32_t ticks)
 	{
@@ -396,7 +397,7 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 #endif
 	// the wave's running counters over its tiles: summed over the lanes after every tile (a handful of
 	// shuffles per tile) and kept wave-uniform, so that no lane carries them through the bounce loop
-	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0;
+	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0, tiles_done = 0;
 	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
 		age.tile_start();
@@ -433,6 +434,8 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		w_evals += (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
 		tiles.tile_took(age.ticks_since_start());
+		// make room for a younger wave (pixel_launch_blocks, sdfr_kernels.h) -- but never with claimed tiles in hand
+		if (rm.retire_after && ++tiles_done >= rm.retire_after && !tiles.holds_claimed_tiles()) break;
 #ifdef SDFR_WAVE_TRACE
 		trace_tiles++;
 #endif

@@ -81,6 +81,13 @@ struct PersistentTiles<Scene, typename VoidOf<decltype(Scene::persistent_tiles)>
 	static constexpr bool value = Scene::persistent_tiles;
 };
 
+// tiles a wave of the scene's persistent launch renders before it makes room for a younger one (pixel_launch_blocks,
+// sdfr_kernels.h); a scene may say `static constexpr int retire_after = n;` (0 = never)
+template <class Scene, class = void>
+struct RetireAfter { static constexpr int value = 8; };
+template <class Scene>
+struct RetireAfter<Scene, typename VoidOf<decltype(Scene::retire_after)>::type> { static constexpr int value = Scene::retire_after; };
+
 struct PixelCounters
 {
 	uint32_t rays, march_evals, hits;

@@ -305,6 +305,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
+	static constexpr int retire_after = 4; // its tiles are very uneven: configuration 4 1.60 (never) / 1.50 (4) / 1.55 (8) ms
 	static constexpr int waves_per_simd = 8; // configuration 4 1.507 -> 1.490 ms (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
@@ -350,14 +351,35 @@ struct SceneFractal
 	// 0.866, 0.955, 0.985, ... < 1.  fold() is the exact distance to the union of the boxes (the
 	// folds are isometries), so it is >= |p - c| - 1 and can be skipped when that is not below the
 	// floor's distance (0.01 of slack; checked numerically in tests/test_scene_bounds_cpu.py).
+	// The same bound level by level: levels i .. 7 as a function of the folded, scaled point q_i are the fractal itself
+	// with 8 - i levels, shrunk by 3^i -- so they are >= (|q_i| - 1) / 3^i, and once that is not below the running minimum
+	// (the floor included) the remaining levels cannot lower it: min() over the same values, cut short.  0.01 of slack in
+	// q_i's units (rounding moves q_i by ~1e-6 |q_i|).  Only for the distance: material() wants the level that touched.
+	static SDF_HD float fold_below(vec3 p, float d)
+	{
+		const float size = 1.f;
+		vec3 q = p - V3(0.f, 1.f, 0.f);
+		float scale = 1.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+		{
+			const float k = max1(d, 0.f) * scale + (1.f + 0.01f);
+			if (dot(q, q) >= k * k) return d;
+			d = min1(d, div_c(sd_box(q, V3s(size * 0.5f)), scale, 1.0f / scale));
+			q = abs(q);
+			sort3_desc(q.y, q.x, q.z);
+			q.y = q.y - size * 2.f / 3.f;
+			q.y = q.y + size / 3.f;
+			sort3_desc(q.y, q.x, q.z);
+			q.y = q.y - size / 3.f;
+			q = q * 3.f;
+			scale = scale * 3.f;
+		}
+		return d;
+	}
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		const vec3 c = p - V3(0.f, 1.f, 0.f);
-		const float k = max1(d, 0.f) + (1.f + 0.01f);
-		if (dot(c, c) >= k * k) return d;
-		float lvl;
-		return min1(d, fold(p, &lvl));
+		return fold_below(p, min1(3e38f, ground_dist(p, fast, R.ground)));
 	}
 	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
 	{
@@ -533,6 +555,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }

@@ -149,6 +149,18 @@ extern "C" long long hostsim_check_fractal_bounds(long long n, unsigned seed)
 		float lvl;
 		const float d = SceneFractal::fold(p, &lvl);
 		if (d < (r - 1.f) - 1e-5f) ++bad;
+		// the level-by-level cut gives the bits of the full fold, whatever the running minimum it starts from
+		const float start = (i % 3 == 0) ? 3e38f : ((i % 3 == 1) ? rnd() * 2.f : d * (0.5f + rnd()));
+		if (f32_bits(SceneFractal::fold_below(p, start)) != f32_bits(min1(start, d))) ++bad;
+	}
+	// and close to the surface, where every level counts
+	for (long long i = 0; i < n / 4; ++i)
+	{
+		const vec3 p = V3((rnd() - 0.5f) * 1.2f, 1.f + (rnd() - 0.5f) * 1.2f, (rnd() - 0.5f) * 1.2f);
+		float lvl;
+		const float d = SceneFractal::fold(p, &lvl);
+		const float start = (i & 1) ? 3e38f : rnd() * 0.2f;
+		if (f32_bits(SceneFractal::fold_below(p, start)) != f32_bits(min1(start, d))) ++bad;
 	}
 	return bad;
 }

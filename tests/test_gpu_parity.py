@@ -411,6 +411,38 @@ def test_launch_modes_give_the_same_frame(renderer, oracle, scene):
         renderer.setLaunchMode(sp.LAUNCH_AUTO)
 
 
+@pytest.mark.parametrize("scene", ["fast_sphere", "labyrinth"])
+def test_persistent_launch_at_full_size_loses_no_tile(renderer, oracle, scene):
+    """3840 x 2160: 129 600 tiles for ~7 000 resident waves.  With cheap tiles (fast_sphere) a wave claims up to eight per
+    atomic, and a wave retires after a number of tiles to make room for a younger one -- never while it still holds
+    claimed tiles (a wave that did left holes in the frame).  Same bits as one wave per tile, every pixel counted, twice."""
+    import torch
+    import sdf_playground_amd as sp
+
+    _setup(renderer, oracle, scene, 0.75)
+    w, h = 3840, 2160
+    cam = sp.Camera()
+    cam.SetEye((1.2, 5.0, 0.4))
+    cam.SetDirection((0.9, -0.35, 0.3))
+    cam.SetAspect(w / h)
+    renderer.setCamera(cam)
+    try:
+        renderer.setLaunchMode(sp.LAUNCH_PER_TILE)
+        want = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        renderer.render(None, w, h, out=want)
+        ref = renderer.getStats()
+        assert ref.pixels == w * h
+        renderer.setLaunchMode(sp.LAUNCH_PERSISTENT)
+        for rep in range(2):
+            img = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+            renderer.render(None, w, h, out=img)
+            s = renderer.getStats()
+            assert (s.pixels, s.rays, s.march_evals, s.hits) == (ref.pixels, ref.rays, ref.march_evals, ref.hits), rep
+            assert torch.equal(img.view(torch.int32), want.view(torch.int32)), rep
+    finally:
+        renderer.setLaunchMode(sp.LAUNCH_AUTO)
+
+
 def test_registered_host_target(renderer, oracle):
     """sdfr_register_host_target: a page-locked host image is filled with the same bits, frame after frame; after
     unregistering, ordinary host destinations still work"""
