@@ -116,3 +116,28 @@ def test_run_time_scene_renders_in_strips(renderer):
     renderer.assembleStrips(w, h, world, gathered, out)
     renderer.sync()
     assert np.array_equal(out.cpu().numpy().view(np.uint32), full.view(np.uint32))
+
+
+def test_run_time_scene_in_the_persistent_launch(renderer):
+    """a run-time scene is launched one wave per tile unless asked otherwise; asked, it runs the persistent launch of the
+    built-in scenes (tile queue, waves that retire): same frame, same counters, at a size where waves take many tiles"""
+    import sdf_playground_amd as sp
+    import torch
+
+    renderer.initShaderSource("pendulum", SCENES_DIR + "/pendulum.scene.h")
+    renderer.setParameters(0.4)
+    w, h = 2560, 1440
+    cam = _pendulum_camera(sp)
+    cam.SetAspect(w / h)
+    try:
+        want = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        renderer.render(cam, w, h, out=want)
+        ref = renderer.getStats()
+        renderer.setLaunchMode(sp.LAUNCH_PERSISTENT)
+        got = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        renderer.render(cam, w, h, out=got)
+        s = renderer.getStats()
+        assert (s.pixels, s.rays, s.march_evals, s.hits) == (ref.pixels, ref.rays, ref.march_evals, ref.hits) and s.pixels == w * h
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    finally:
+        renderer.setLaunchMode(sp.LAUNCH_AUTO)
