@@ -165,7 +165,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
-	static constexpr int waves_per_simd = 6; // 22 instead of 38 spilled registers: configuration 3 1.393 -> 1.371 ms (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 5; // 96 registers, 5 spilled; configuration 3 with waves that retire: 1.37 (5) / 1.41 (6) / 1.38 (7) ms, four runs each (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -306,7 +306,7 @@ struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
 	static constexpr int retire_after = 4; // its tiles are very uneven: configuration 4 1.60 (never) / 1.50 (4) / 1.55 (8) ms
-	static constexpr int waves_per_simd = 8; // configuration 4 1.507 -> 1.490 ms (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 6; // configuration 4 with waves that retire: 1.47 (5) / 1.45 (6) / 1.48 (8) ms (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
