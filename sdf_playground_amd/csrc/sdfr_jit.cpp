@@ -217,7 +217,8 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap, &cursors};
 	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
-	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors);
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? ((n_work + bt - 1u) / bt) / tiles_x : 0u, (unsigned long long)n_work);
 }
 
 } // namespace sdfr

@@ -48,7 +48,9 @@ hipError_t launch_selftest_math(int what, float c, unsigned long long *d_mismatc
 hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_work, const WavefrontWorkspace &ws, uint32_t *pixel_stats, hipStream_t stream);
 
 // folds the per-block partial sums of a pixel-schedule launch into `totals` and puts the tile cursors back to zero
-hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors);
+// feedback_rows: tile rows of the launch if it was a persistent one whose rows should be re-ordered for the next frame (else 0)
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,
+	uint32_t feedback_rows, unsigned long long frame_pixels);
 int pixel_tile_cursor_words();
 // how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per
 // tile.  launch_mode: 0 = the scene's own default (PersistentTiles), 1 = one wave per tile, 2 = persistent;

@@ -49,16 +49,50 @@ uint32_t launch_work_items(int width, const RowMap &rm)
 #define SDFR_REDUCE_THREADS 256
 #define SDFR_REDUCE_BLOCKS 64
 __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals,
-	uint32_t *tile_cursors)
+	uint32_t *tile_cursors, uint32_t feedback_rows, unsigned long long frame_pixels)
 {
 	// the pixel kernel before this one has drained its tile cursors: back to zero for the next launch
 	if (blockIdx.x == 0 && threadIdx.x < SDFR_TILE_CURSORS) tile_cursors[threadIdx.x * SDFR_TILE_CURSOR_STRIDE] = 0u;
+	// Row feedback (sdfr_pixel_kernel.h): the last block does nothing but sort the tile rows by this frame's cost, dearest
+	// first, into the order the next frame's launch hands them out in.  Rank by counting (rows <= 512: a microsecond).
+	if (blockIdx.x == gridDim.x - 1u && gridDim.x > 1u)
+	{
+		__shared__ uint32_t cost[SDFR_ROW_FEEDBACK_MAX];
+		__shared__ unsigned long long frame_rays;
+		uint32_t *meta = tile_cursors + SDFR_ROW_META, *row_cost = tile_cursors + SDFR_ROW_COST, *row_order = tile_cursors + SDFR_ROW_ORDER;
+		uint32_t *row_rays = tile_cursors + SDFR_ROW_RAYS;
+		uint32_t rows = feedback_rows <= SDFR_ROW_FEEDBACK_MAX ? feedback_rows : 0u;
+		if (threadIdx.x == 0) frame_rays = 0ull;
+		__syncthreads();
+		unsigned long long my_rays = 0ull;
+		for (uint32_t i = threadIdx.x; i < SDFR_ROW_FEEDBACK_MAX; i += SDFR_REDUCE_THREADS)
+		{
+			cost[i] = i < rows ? row_cost[i] : 0u;
+			my_rays += i < rows ? row_rays[i] : 0u;
+			row_cost[i] = 0u;
+			row_rays[i] = 0u;
+		}
+		atomicAdd(&frame_rays, my_rays);
+		__syncthreads();
+		// many rays per pixel: leave the rows in image order (SDFR_ROW_FEEDBACK_MAX_RAYS); every tile added 64 to its row's cost
+		if (frame_rays > (unsigned long long)SDFR_ROW_FEEDBACK_MAX_RAYS * frame_pixels) rows = 0u;
+		for (uint32_t i = threadIdx.x; i < rows; i += SDFR_REDUCE_THREADS)
+		{
+			const uint32_t mine = cost[i];
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < rows; ++j) rank += (cost[j] > mine || (cost[j] == mine && j < i)) ? 1u : 0u;
+			row_order[rank] = i;
+		}
+		if (threadIdx.x == 0) *meta = rows; // 0: no order for the next launch
+		return;
+	}
+	const uint32_t fold_blocks = gridDim.x > 1u ? gridDim.x - 1u : 1u;
 	__shared__ unsigned long long acc[4];
 	if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
 	__syncthreads();
 	unsigned long long s[4] = {0ull, 0ull, 0ull, 0ull};
 	const ulonglong4 *src = reinterpret_cast<const ulonglong4 *>(partials);
-	const uint32_t stride = gridDim.x * SDFR_REDUCE_THREADS;
+	const uint32_t stride = fold_blocks * SDFR_REDUCE_THREADS;
 	for (uint32_t base = blockIdx.x * SDFR_REDUCE_THREADS + threadIdx.x; base < n; base += stride * 4)
 	{
 		ulonglong4 v[4];
@@ -84,7 +118,7 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 	__syncthreads();
 	if (threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(totals) + threadIdx.x, acc[threadIdx.x]);
 }
-int pixel_tile_cursor_words() { return SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE; }
+int pixel_tile_cursor_words() { return (int)SDFR_CURSOR_WORDS; }
 
 PixelLaunchMode pixel_launch_mode(int launch_mode, bool scene_default_persistent, int scene_retire_after)
 {
@@ -108,12 +142,16 @@ uint32_t pixel_launch_blocks(const PixelLaunchMode &mode, uint32_t tiles, uint32
 	return blocks < tiles ? blocks : tiles;
 }
 
-hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors)
+hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,
+	uint32_t feedback_rows, unsigned long long frame_pixels)
 {
+	static const bool feedback = [] { const char *e = getenv("SDFR_TILE_FEEDBACK"); return e ? atoi(e) != 0 : true; }(); // developer knob
 	uint32_t blocks = (n_blocks + SDFR_REDUCE_THREADS * 4 - 1) / (SDFR_REDUCE_THREADS * 4);
 	if (blocks > SDFR_REDUCE_BLOCKS) blocks = SDFR_REDUCE_BLOCKS;
 	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals, tile_cursors);
+	// one more block: it sorts the tile rows for the next frame while the others fold the counters
+	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks + 1), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals, tile_cursors,
+		feedback ? feedback_rows : 0u, frame_pixels);
 	return hipGetLastError();
 }
 

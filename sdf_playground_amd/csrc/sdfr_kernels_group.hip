@@ -295,7 +295,8 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rows, n_work, out, format, pixel_stats, ws.partials, totals,
 		ws.ray_queue, ws.capacity, mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr);
-	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors);
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? tiles_blocks / tiles_x : 0u, (unsigned long long)n_work);
 }
 
 template <class Scene, bool DBG>

@@ -54,18 +54,25 @@ struct PixelCoord
 	int px, py;   // in the full frame
 	uint32_t pid; // index in this launch's (compact) image
 };
-__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc)
+// which tile row the ty-th row to be handed out is: the launch's affine order (RowMap), or -- `order` -- last frame's
+// rows sorted by what they cost (row feedback, below)
+__device__ __forceinline__ uint32_t handed_out_row(const RowMap &rm, uint32_t ty, const uint32_t *order)
+{
+	if (rm.tile_row_mul != 1u || rm.tile_row_add != 0u)
+	{
+		const uint32_t th_log2 = 6u - (uint32_t)rm.tile_w_log2;
+		const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
+		return (ty * rm.tile_row_mul + rm.tile_row_add) % tiles_y;
+	}
+	return order ? order[ty] : ty;
+}
+__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc, const uint32_t *order = nullptr)
 {
 	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << tw_log2) - 1u) >> tw_log2;
 	const uint32_t tile = w >> 6, lane = w & 63u;
 	const uint32_t tx = tile % tiles_x;
-	uint32_t ty = tile / tiles_x;
-	if (rm.tile_row_mul != 1u || rm.tile_row_add != 0u) // the order the tile rows are handed out in (RowMap)
-	{
-		const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
-		ty = (ty * rm.tile_row_mul + rm.tile_row_add) % tiles_y;
-	}
+	const uint32_t ty = handed_out_row(rm, tile / tiles_x, order);
 	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
 	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
@@ -321,6 +328,23 @@ struct LdsCachedRayStore
 #endif
 #define SDFR_TILE_FAST_TICKS 1000u // of the 100-MHz clock: a tile rendered this quickly (10 us) makes the wave claim more at once
 #define SDFR_NO_TILE 0xffffffffu
+// Row feedback.  The frame ends when the last wave ends, so the tiles handed out last should be the cheap ones: every
+// tile adds its march evaluations to its tile row's cost, the fold kernel that follows the launch sorts the rows by cost
+// (dearest first) into the order the NEXT frame's launch hands them out in, and clears the costs.  Frames of a sequence
+// resemble each other row by row (sky, horizon, floor) even when the camera turns.  State lives behind the tile cursors:
+// [META] rows the order was made for (anything else, e.g. 0 before the first frame: hand out top to bottom),
+// [COST ...] this frame's cost per row, [ORDER ...] the permutation.  Persistent launches of up to 512 tile rows.
+#define SDFR_ROW_FEEDBACK_MAX 512u
+#define SDFR_ROW_META (SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE)
+#define SDFR_ROW_COST (SDFR_ROW_META + 32u)
+#define SDFR_ROW_ORDER (SDFR_ROW_COST + SDFR_ROW_FEEDBACK_MAX)
+#define SDFR_ROW_RAYS (SDFR_ROW_ORDER + SDFR_ROW_FEEDBACK_MAX)
+#define SDFR_CURSOR_WORDS (SDFR_ROW_RAYS + SDFR_ROW_FEEDBACK_MAX)
+// Not for frames with many rays per pixel (above SDFR_ROW_FEEDBACK_MAX_RAYS on average: the depth-4 / 8-light
+// configurations): their pixels keep queued rays in HBM, gigabytes per frame, and rows rendered out of image order
+// scatter that traffic -- measured +2.7 % on lense with 8 lights and +1.6 % on gems, against -3.6 % on the labyrinth,
+// -2 % on cube_sea at 1080p and -7 % on the fractal.  [RAYS ...]: this frame's rays per row, for that decision.
+#define SDFR_ROW_FEEDBACK_MAX_RAYS 4u
 struct TileQueue
 {
 	uint32_t *cursors;
@@ -398,13 +422,18 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 	// the wave's running counters over its tiles: summed over the lanes after every tile (a handful of
 	// shuffles per tile) and kept wave-uniform, so that no lane carries them through the bounce loop
 	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0, tiles_done = 0;
+	// row feedback (see SDFR_ROW_META): which rows come first, where this frame's costs go
+	const uint32_t fb_tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	const uint32_t fb_rows = (n_work >> 6) / fb_tiles_x;
+	const bool fb_on = tile_cursors != nullptr && fb_rows <= SDFR_ROW_FEEDBACK_MAX;
+	const uint32_t *row_order = fb_on && tile_cursors[SDFR_ROW_META] == fb_rows ? tile_cursors + SDFR_ROW_ORDER : nullptr;
 	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
 		age.tile_start();
 		PixelCounters pcnt = {};
 		uint32_t pix = 0;
 		PixelCoord pc;
-		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc))
+		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc, row_order))
 		{
 			GlobalRayStore backing = {ray_queue, cap, pc.pid};
 			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
@@ -433,6 +462,12 @@ __device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, 
 		w_rays += (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
 		w_evals += (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+		if (fb_on && (threadIdx.x & 63u) == 0)
+		{
+			const uint32_t row = handed_out_row(rm, tile / fb_tiles_x, row_order);
+			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u);
+			atomicAdd(tile_cursors + SDFR_ROW_RAYS + row, b);
+		}
 		tiles.tile_took(age.ticks_since_start());
 		// make room for a younger wave (pixel_launch_blocks, sdfr_kernels.h) -- but never with claimed tiles in hand
 		if (rm.retire_after && ++tiles_done >= rm.retire_after && !tiles.holds_claimed_tiles()) break;
