@@ -56,7 +56,6 @@ struct SceneCube
 struct SceneGyroid
 {
 	static const char *name() { return "gyroid"; }
-	static constexpr bool persistent_tiles = true; // with waves that retire after 8 tiles: 0.857 -> 0.772 ms at 4K (profiles/r02_launch_modes.txt)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -91,7 +90,6 @@ struct SceneGyroid
 struct SceneBasicTransparency
 {
 	static const char *name() { return "basic_transparency"; }
-	static constexpr bool persistent_tiles = true; // with waves that retire after 8 tiles: 0.838 -> 0.776 ms at 4K (profiles/r02_launch_modes.txt)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -135,7 +133,6 @@ struct SceneBasicTransparency
 struct SceneBasicClouds
 {
 	static const char *name() { return "basic_clouds"; }
-	static constexpr bool persistent_tiles = true; // with waves that retire after 8 tiles: 0.580 -> 0.515 ms at 4K (profiles/r02_launch_modes.txt)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return "VAR_offset(min = -5, max = 5, step = 0.05)"; }
 	static SDF_HD void prepare(FrameU &) {}

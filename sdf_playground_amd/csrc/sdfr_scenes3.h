@@ -89,7 +89,6 @@ struct SceneFractal2
 struct SceneShell
 {
 	static const char *name() { return "shell"; }
-	static constexpr bool persistent_tiles = true; // with waves that retire after 8 tiles: 0.455 -> 0.417 ms at 4K (profiles/r02_launch_modes.txt)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
