@@ -271,7 +271,7 @@ def parse_args(argv=None):
                          "peers copy their strips into rank 0's buffer through hipIpc mappings (sdfr_render_gather_peer), control over gloo")
     ap.add_argument("--wire", default="f16", choices=["f16", "f32"],
                     help="N > 1: f16 = strips and image in the reference's RGBA16F target format (7 B/pixel on the links); f32 = lossless fp32 (13 B/pixel)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="N > 1: handles / streams the frames alternate between")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="N > 1: handles / streams the frames alternate between")
     ap.add_argument("--dry-launch", action="store_true", help="start the ranks, let each report its environment over gloo, touch no GPU (CPU test of the launcher)")
     return ap.parse_args(argv)
 
