@@ -60,6 +60,7 @@ def run(cases, seed, size, scenes=None, verbose=False):
                     r.setValue(name, v)
             schedule = int(rng.integers(0, 2))
             r.setSchedule(schedule)
+            r.setLaunchMode(int(rng.choice([sp.LAUNCH_AUTO, sp.LAUNCH_PER_TILE, sp.LAUNCH_PERSISTENT])))  # pixel schedule: how the tiles reach the waves
             img, st = r.render(cam, W, H, pixel_stats=True)
             ref, rst, _ = po.render(scene, f, stats=True)
             n += 1
