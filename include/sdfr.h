@@ -140,6 +140,13 @@ typedef enum sdfr_launch_mode
 	SDFR_LAUNCH_PERSISTENT = 2
 } sdfr_launch_mode;
 int sdfr_set_launch_mode(sdfr_renderer *r, int mode);
+/* Step shortcuts (on by default; SDFR_STEP_SHORTCUTS=0 in the environment makes off the default): a ray for which its
+   scene can tell that nothing lies ahead any more (cube_sea: above the cubes and not descending) is booked as the miss it
+   is going to be without marching its remaining steps.  No pixel and no ray or hit count changes; sdfr_stats.march_evals
+   and the per-pixel step counters then fall short of the reference's step counts.  Off: every step is marched, the
+   counters equal the reference's (what the parity tests compare).  The reference has no counterpart: it marches on
+   (pshader_sdf.hlsl:179-220). */
+int sdfr_set_step_shortcuts(sdfr_renderer *r, int enabled);
 /* per-round HIP events around the march and shade kernels (sdfr_stats.ms_march / ms_shade); off by default */
 int sdfr_set_profiling(sdfr_renderer *r, int enabled);
 

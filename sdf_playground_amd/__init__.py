@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_rank", "sdfr_comm_world",
-    "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode",
+    "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
     "sdfr_register_host_target", "sdfr_peer_region_create", "sdfr_peer_region_open", "sdfr_peer_region_close", "sdfr_peer_region_status",
     "sdfr_render_gather_peer",
 ]
@@ -137,6 +137,7 @@ def load_library():
     L.sdfr_set_schedule.argtypes = [vp, ci]
     L.sdfr_set_profiling.argtypes = [vp, ci]
     L.sdfr_set_launch_mode.argtypes = [vp, ci]
+    L.sdfr_set_step_shortcuts.argtypes = [vp, ci]
     L.sdfr_register_host_target.argtypes = [vp, vp, ctypes.c_size_t]
     L.sdfr_peer_region_create.argtypes = [vp, ctypes.c_size_t, ci, vp]
     L.sdfr_peer_region_open.argtypes = [vp, vp]
@@ -380,6 +381,11 @@ class SDFRenderer:
     def setLaunchMode(self, mode):
         """LAUNCH_AUTO (the scene's own choice), LAUNCH_PER_TILE or LAUNCH_PERSISTENT (sdfr_set_launch_mode)."""
         self._check(self._L.sdfr_set_launch_mode(self._h, int(mode)))
+
+    def setStepShortcuts(self, enabled):
+        """sdfr_set_step_shortcuts: rays their scene knows to be misses already stop marching (same pixels, fewer steps
+        counted); off = every step marched, step counters equal the reference's."""
+        self._check(self._L.sdfr_set_step_shortcuts(self._h, 1 if enabled else 0))
 
     def setProfiling(self, enabled):
         self._check(self._L.sdfr_set_profiling(self._h, 1 if enabled else 0))

@@ -117,6 +117,7 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 		int v = atoi(t);
 		if (v >= 3 && v <= 6) r->tile_w_log2 = v;
 	}
+	if (const char *t = getenv("SDFR_STEP_SHORTCUTS")) r->step_shortcuts = atoi(t) != 0; // default of sdfr_set_step_shortcuts
 	if (const char *t = getenv("SDFR_TILE_ORDER")) // developer knob: 0 top to bottom, 1 bottom to top, 2 interleaved rows
 		r->tile_order = atoi(t);
 	frame_defaults(r->U);
@@ -434,6 +435,13 @@ int sdfr_set_launch_mode(sdfr_renderer *r, int mode)
 	return SDFR_OK;
 }
 
+int sdfr_set_step_shortcuts(sdfr_renderer *r, int enabled)
+{
+	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+	r->step_shortcuts = enabled != 0;
+	return SDFR_OK;
+}
+
 int sdfr_set_schedule(sdfr_renderer *r, int schedule)
 {
 	if (!r || (schedule != SDFR_SCHEDULE_WAVEFRONT && schedule != SDFR_SCHEDULE_PIXEL)) return SDFR_ERR_INVALID_ARGUMENT;
@@ -492,6 +500,7 @@ static int latch_frame(sdfr_renderer *r, int width, int height)
 	U.show_objects = val("show_objects");
 	for (int i = 0; i < SDFR_MAX_SCENE_VARS; ++i) U.scene_var[i] = 0.f;
 	for (size_t k = 0; k < r->scene_var_slots.size(); ++k) U.scene_var[k] = val(r->scene_var_slots[k].c_str());
+	U.step_shortcuts = r->step_shortcuts ? 1 : 0;
 	frame_derive(U, r->scene);
 	if (r->scene == SDFR_SCENE_COUNT) SDFR_HIP(jit_prepare(r->jit, U, r->stream));
 	return SDFR_OK;

@@ -37,6 +37,10 @@ struct FrameU
 	// EXTENSION, not in the reference (SURVEY.md 8d cfg 3 "2 reflection bounces"): reflection colour given to
 	// marble materials; 0 = reference behaviour
 	float extension_marble_reflection;
+	// Not a change of any pixel: a ray for which the scene says that nothing lies ahead any more (Scene::ray_escapes)
+	// is booked as the miss it is going to be without marching the remaining steps.  The per-pixel count of march
+	// evaluations then falls short of the reference's; 0 = march every step (the counters equal the oracle's).
+	int step_shortcuts;
 };
 
 // One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct

@@ -44,6 +44,7 @@ struct sdfr_renderer
 	hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 	hipEvent_t ev_post[3] = {}; // before / between / after the two post-processing kernels
 	bool have_post = false;
+	bool step_shortcuts = true; // sdfr_set_step_shortcuts
 	unsigned char *d_post_flags = nullptr; // per row segment: did the horizontal bloom pass store any light (sdfr_post.hip)
 	size_t post_flag_bytes = 0;
 	double ms_setup = 0.0;      // host time of the last latch_frame (+ Scene::prepare of a run-time scene)

@@ -88,6 +88,23 @@ struct RetireAfter { static constexpr int value = 8; };
 template <class Scene>
 struct RetireAfter<Scene, typename VoidOf<decltype(Scene::retire_after)>::type> { static constexpr int value = Scene::retire_after; };
 
+// A scene may declare `static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)`: true only if
+// NOTHING of the scene lies on the ray from p onwards -- then the ray is a miss already (an escaped shadow ray delivers
+// its light, any other ray sees the background, whose colour does not depend on the step count in such a scene), and the
+// pixel kernel stops marching it (FrameU::step_shortcuts; never in the debug-plane build, whose plane is an extra object).
+template <class Scene, class = void>
+struct RayEscapes
+{
+	static constexpr bool available = false;
+	template <class R> static SDF_HD bool test(const FrameU &, const R &, vec3, vec3) { return false; }
+};
+template <class Scene>
+struct RayEscapes<Scene, typename VoidOf<decltype(&Scene::ray_escapes)>::type>
+{
+	static constexpr bool available = true;
+	template <class R> static SDF_HD bool test(const FrameU &U, const R &r, vec3 p, vec3 dir) { return Scene::ray_escapes(U, r, p, dir); }
+};
+
 struct PixelCounters
 {
 	uint32_t rays, march_evals, hits;
@@ -143,11 +160,27 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		March m = march_begin(ray.pos, ray.dir);
 		int status;
 		const uint32_t evals_before = cnt.march_evals;
+		const bool shortcuts = !DBG && RayEscapes<Scene>::available && U.step_shortcuts != 0 && inside_sign > 0.f; // (a ray inside a refracting body ends on its surface)
 		do
 		{
 			march_pre(m);
+			// Step shortcut.  Only a sample the march will not take back may end the ray: an unrelaxed one (factor 1: the
+			// first three samples and everything after a rewind) is final as it stands, a relaxed one once its own distance
+			// shows that it did not over-step (march_advance's test) -- an over-stepped sample can lie beyond an obstacle
+			// that the rewound march then hits.
+			const bool escaped = shortcuts && RayEscapes<Scene>::test(U, R, march_pos(m), ray.dir);
+			if (escaped && m.factor == 1.f)
+			{
+				status = MARCH_MISS; // what the remaining steps would come to
+				break;
+			}
 			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
 			cnt.march_evals++;
+			if (escaped && !((m.last_d + d) < m.last_d * m.factor))
+			{
+				status = MARCH_MISS;
+				break;
+			}
 			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
 		} while (status == MARCH_CONTINUE);
 		SDFR_CLK(c1);

@@ -67,7 +67,7 @@ struct SceneCubeSea
 	// below 2.1) and, as far as 250 000 random divisors in [2^-66, 2] times every numerator can
 	// tell, any divisor (tools/divsweep_long.py; the ground plane relies on the same fact).
 	// Directions closer to an axis than 2^-60, and exact zeros, keep the IEEE division.
-	struct RayInv { GroundInv ground; vec2 barrier; vec2 rdir; bool exact_x, exact_z; };
+	struct RayInv { GroundInv ground; vec2 barrier; vec2 rdir; bool exact_x, exact_z, rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
@@ -77,8 +77,14 @@ struct SceneCubeSea
 		r.exact_x = abs1(dir.x) >= 8.6736174e-19f; // 2^-60
 		r.exact_z = abs1(dir.z) >= 8.6736174e-19f;
 		r.rdir = V2(r.exact_x ? rcp1(dir.x) : 0.f, r.exact_z ? rcp1(dir.z) : 0.f);
+		r.rising = dir.y >= 0.f;
 		return r;
 	}
+	// Above the cubes' slab (cube_lower_bound: they end at y = 3.65) a ray that does not descend has the floor behind it
+	// and every cube below it for good: only the cell guard still stops it, once per cell wall, out to the range of 100 --
+	// two thirds of this scene's march steps (sky-bound primary and reflection rays, shadow rays towards the sun once
+	// they have cleared the cubes).
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 3.66f; }
 	static SDF_HD float guard_quotient(float num, float den, float rden, bool exact)
 	{
 		if (exact) return div_c(num, den, rden);
@@ -174,7 +180,7 @@ struct SceneLabyrinth
 
 	static SDF_HD float fire_cone(vec3 p) { return sd_round_cone(p, V3(0.f, 1.1f, 0.f), V3(0.f, 1.6f, 0.f), 0.15f, 0.1f); }
 
-	struct RayInv { GroundInv ground; bool skip_fire; };
+	struct RayInv { GroundInv ground; bool skip_fire, rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
@@ -182,8 +188,14 @@ struct SceneLabyrinth
 		// a ray continuing through a transparent surface ignores the fire it just left
 		// (OBJECT_TRANSPARENT, pshader_sdf.hlsl:80; sdf_scene_labyrinth.hlsl:55,62)
 		r.skip_fire = f.has_transparent && fire_cone(f.last_transparent_pos) < SDFR_DIST_EPS;
+		r.rising = dir.y >= 0.f;
 		return r;
 	}
+	// Nothing of the labyrinth reaches above y = 4: the walls are boxes from 0 to 4, the vase ends at 2.4, stick and flame
+	// lie in the ball about (5.2, 2.9, 3) of radius 0.9 (see dist).  A ray above that height that does not descend has the
+	// floor behind it as well: the sky-bound primary rays of the upper part of the picture (they start above the walls:
+	// no step at all) and every shadow ray once it has cleared the walls.
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 4.01f; }
 
 	static SDF_HD float vase(vec3 p)
 	{
@@ -311,13 +323,16 @@ struct SceneFractal
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
-	struct RayInv { GroundInv ground; };
+	struct RayInv { GroundInv ground; bool rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
+		r.rising = dir.y >= 0.f;
 		return r;
 	}
+	// every box lies in the unit ball about (0, 1, 0) (see dist): nothing above y = 2, and the floor is behind a ray that does not descend
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 2.01f; }
 	// 8-level recursive fold; returns the distance, and the level that first touched
 	static SDF_HD float fold(vec3 p, float *level_hit)
 	{
@@ -566,13 +581,17 @@ struct SceneGems
 		U.su[SU_ROT_S] = sc.x;
 		U.su[SU_ROT_C] = sc.y;
 	}
-	struct RayInv { GroundInv ground; };
+	struct RayInv { GroundInv ground; bool rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
+		r.rising = dir.y >= 0.f;
 		return r;
 	}
+	// gems() is a smooth maximum of three planes, never below any of them (the blend only adds): >= plane3 = p.y - 1.13.
+	// Above y = 1.14 a ray that does not descend stays 0.01 clear of every gem, and the floor is behind it.
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 1.14f; }
 	static SDF_HD float gems(const FrameU &U, vec3 p, float *ring_index)
 	{
 		vec2 xz = rot2(V2(p.x, p.z), U.su[SU_ROT_S], U.su[SU_ROT_C]);

@@ -227,8 +227,11 @@ struct SceneTerrain
 		U.su[SU_ROT_S] = sc.x;
 		U.su[SU_ROT_C] = sc.y;
 	}
-	struct RayInv { int unused; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
+	struct RayInv { bool rising; };
+	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &) { RayInv r; r.rising = dir.y >= 0.f; return r; }
+	// shape() = max(terrain, box of half size 5 about the origin) >= the box's distance >= p.y - 5: nothing above y = 5,
+	// and this scene has no other object (no floor either)
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 5.01f; }
 	static SDF_HD float lattice_noise(vec3 p) { return frac1(sin1(dot(p, V3(12.9898f, 78.233f, 34.531247f))) * 43758.5453f); }
 	static SDF_HD float corner_sphere(vec3 cell, vec3 p, vec3 off)
 	{

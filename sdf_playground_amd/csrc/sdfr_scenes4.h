@@ -17,14 +17,18 @@ struct SceneTree
 	enum { SU_DRIFT = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
 
-	struct RayInv { GroundInv ground; vec2 dir2; };
+	struct RayInv { GroundInv ground; vec2 dir2; bool rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
 		r.dir2 = normalize(V2(dir.x, dir.z));
+		r.rising = dir.y >= 0.f;
 		return r;
 	}
+	// the scene itself looks at its trees only below the canopy's bounding plane (dist: bounding < 0.1, i.e. y < 2.1);
+	// above it the distance is min(that plane, floor), both behind a ray that does not descend
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 2.11f; }
 
 	// a truncated cone standing on the origin
 	static SDF_HD float branch(vec3 p, float h2, float r1, float r2)

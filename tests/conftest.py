@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The parity tests compare per-pixel step counters with the oracle's: every step is marched unless a test asks otherwise
+# (sdfr_set_step_shortcuts; tests/test_gpu_shortcuts.py covers the default of the library, shortcuts on).
+os.environ.setdefault("SDFR_STEP_SHORTCUTS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -27,6 +27,7 @@ class FrameU(ctypes.Structure):
         ("ddx", ctypes.c_float), ("ddy", ctypes.c_float), ("sky_s", ctypes.c_float), ("sky_c", ctypes.c_float),
         ("su", ctypes.c_float * 48),
         ("extension_lights", ctypes.c_int), ("ext_light", (ctypes.c_float * 6) * 7), ("extension_marble_reflection", ctypes.c_float),
+        ("step_shortcuts", ctypes.c_int),
     ]
 
 

@@ -174,3 +174,27 @@ def test_tree_border_skip_is_invisible(oracle):
         img, st = hostsim.render("tree", hostsim.frame_from_oracle(f))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
         assert np.array_equal(st, rst)
+
+
+def test_cube_sea_escape_rule_changes_no_pixel(oracle):
+    """FrameU::step_shortcuts with SceneCubeSea::ray_escapes (host build of the product's pipeline): same pixels, rays and
+    hits as the oracle from every kind of view, fewer march evaluations"""
+    import hostsim
+
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    views = [((3.0, 4.5, 1.0), (6.0, 3.2, 4.0)), ((0.3, 0.4, 0.2), (2.0, 3.0, 1.5)), ((1.0, 9.0, 1.0), (1.2, 0.0, 1.1)),
+             ((0.0, 2.0, 0.0), (8.0, 2.1, 3.0)), ((2.0, 3.7, 2.0), (9.0, 3.9, 2.5)), ((2.0, 3.655, 2.0), (9.0, 3.67, 2.5))]
+    saved = 0
+    for k, (eye, at) in enumerate(views):
+        f = oracle.default_frame("cube_sea", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.4 * k)
+        f.iter_count, f.max_cost_default = 128, 6
+        ref, rst, _ = oracle.render("cube_sea", f, stats=True)
+        hf = hostsim.frame_from_oracle(f)
+        img, st = hostsim.render("cube_sea", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(st, rst)
+        hf.step_shortcuts = 1
+        img, st = hostsim.render("cube_sea", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+        assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
+        saved += int(rst[..., 1].sum()) - int(st[..., 1].sum())
+    assert saved > 0
