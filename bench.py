@@ -254,6 +254,8 @@ def parse_args(argv=None):
                     help="reflective: config 3 with the labelled extension 'marble reflection_color 0.25' (BASELINE configs[2] as worded); never the headline")
     ap.add_argument("--schedule", default=os.environ.get("SDFR_SCHEDULE", "auto"), choices=["auto", "wavefront", "pixel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-steps", action="store_true",
+                    help="march every step of every ray (sdfr_set_step_shortcuts off): the step counters then equal the reference's; the pixels are the same either way")
     ap.add_argument("--no-second-pass", action="store_true",
                     help="skip the informational two-frames-in-flight pass (N = 1): under a profiler its overlapping kernels would pollute the per-kernel statistics")
     ap.add_argument("--width", type=int, default=0)
@@ -413,6 +415,7 @@ def run(a, world):
         h.initShader(scene)
         h.setLimits(**cfg["limits"])
         h.setSchedule(schedule)
+        h.setStepShortcuts(not a.exact_steps)  # the library's default, said out loud: same pixels, rays and hits; rays known to be misses stop marching
         if distributed:
             # the persistent launch keeps every wave slot of the GPU until its frame ends; the transfer kernels of the
             # frame before (RCCL, another stream) would wait for slots instead of overlapping: one wave per tile here
@@ -692,6 +695,7 @@ def run(a, world):
                 "schedule": schedule_name,
                 "parallelism": "strips%d" % world if distributed else "single",
                 "rays_per_pixel": total_rays / a.steps / (W * H),
+                "step_shortcuts": not a.exact_steps,
             },
         }
         if distributed:
@@ -720,7 +724,7 @@ def run(a, world):
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
                 "kernel_ms": mean_kernel_ms, "kernel_ms_counting_pass": stats_pass_ms, "flops_per_ray": census["flops_per_ray"],
                 "numerator": "ALGORITHMIC: oracle operation census x rays of this launch; it counts every scene evaluation the reference makes, "
-                             "also those the kernel's bounding-volume tests skip, so `frac` is an algorithmic-equivalent rate, not VALU busy time",
+                             "also those the kernel's bounding-volume tests skip and the steps of rays it knows to be misses already (step shortcuts), so `frac` is an algorithmic-equivalent rate, not VALU busy time",
                 "note": "FP32 vector (VALU) issue bounds this path, not HBM or MFMA (SURVEY.md 8d)",
             }
             if pmc:
