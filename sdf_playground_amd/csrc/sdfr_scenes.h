@@ -171,7 +171,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
-	static constexpr int waves_per_simd = 5; // 96 registers, 5 spilled; configuration 3 with waves that retire: 1.37 (5) / 1.41 (6) / 1.38 (7) ms, four runs each (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 6; // configuration 3, final kernels of round 2: 1.35 (4) / 1.31 (5) / 1.28 (6) / 1.32 (7) ms, two runs each; before the step shortcuts 5 was ahead of 6 by 3 %: the choice follows the code (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
