@@ -482,13 +482,48 @@ struct SceneLense
 	// sphere and box of both fields (100 of the ~200 instructions) cannot lower the minimum and are left
 	// out.  0.01 of slack; only below |y| = 1024, where the quantities are O(1000) at most.
 	static SDF_HD float blob_field_lower_bound(float h) { return abs1(h) - 1.11f; }
+	// skip an object that lies in the ball (c, radius) when that ball is not nearer than the running minimum d:
+	// exact distances are >= |p - c| - radius (0.01 of slack, as for the pane)
+	static SDF_HD bool ball_is_farther(vec3 p, vec3 c, float radius, float d)
+	{
+		const vec3 v = p - c;
+		const float k = max1(d, 0.f) + (radius + 0.01f);
+		return dot(v, v) >= k * k;
+	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool)
 	{
-		// min() over the same objects as map(), any order gives the same bits: the cheap ones first
-		vec3 lp = abs(p);
-		lp.z = lp.z - 5.1f;
-		float d = min1(3e38f, max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f)));
-		d = min1(d, sd_sphere(p - V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]), 2.f));
+		// min() over the same objects as map(), any order gives the same bits.  Which order is cheap depends on where the
+		// point is: close to a blob field (|y| > 2.9: the shadow rays creeping away from the blob they started on, a dozen
+		// steps each) the field comes first and lens, light ball (two square roots each) and pane are skipped behind a
+		// squared-distance test against their bounding balls; between the fields they come first and the fields are skipped
+		// behind their slab bounds.
+		const bool far_out = !(abs1(p.y) < 1024.f); // or NaN: no culling there
+		float d = 3e38f;
+		const bool near_a_field = abs1(p.y) > 2.9f && !far_out;
+		if (near_a_field)
+		{
+			vec3 b1 = p - V3(0.f, -5.f, 0.f);
+			if (!(blob_field_lower_bound(b1.y) >= d))
+			{
+				vec2 r1 = op_rep_inf_c(V2(b1.x, b1.z), 3.f, 1.0f / 3.f);
+				d = min1(d, blob(V3(r1.x, b1.y, r1.y)));
+			}
+			vec3 b2 = p - V3(0.f, 5.f, 0.f);
+			if (!(blob_field_lower_bound(b2.y) >= d))
+			{
+				vec2 r2 = op_rep_inf_c(V2(b2.x, b2.z), 10.f, 1.0f / 10.f);
+				d = min1(d, blob(V3(r2.x, b2.y, r2.y)));
+			}
+		}
+		// lens: cut out of the sphere of radius 2 about the origin, so inside that ball; light ball: a sphere of radius 2
+		if (!near_a_field || !ball_is_farther(p, V3(0.f, 0.f, 0.f), 2.f, d))
+		{
+			vec3 lp = abs(p);
+			lp.z = lp.z - 5.1f;
+			d = min1(d, max1(-sd_sphere(lp, 5.f), sd_sphere(p, 2.f)));
+		}
+		const vec3 ball = V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]);
+		if (!near_a_field || !ball_is_farther(p, ball, 2.f, d)) d = min1(d, sd_sphere(p - ball, 2.f));
 
 		vec3 mp = p - V3(0.f, 0.f, -5.f);
 		const float k = max1(d, 0.f) + (2.38f + 0.01f);
@@ -499,8 +534,8 @@ struct SceneLense
 			d = min1(d, sd_box(mp, V3(1.f, 2.f, 0.1f)));
 			d = min1(d, sd_box(mp, V3(1.1f, 2.1f, 0.08f)));
 		}
+		if (near_a_field) return d;
 
-		const bool far_out = !(abs1(p.y) < 1024.f); // or NaN: no culling there
 		vec3 b1 = p - V3(0.f, -5.f, 0.f);
 		if (far_out || !(blob_field_lower_bound(b1.y) >= d))
 		{
