@@ -443,6 +443,35 @@ def test_persistent_launch_at_full_size_loses_no_tile(renderer, oracle, scene):
         renderer.setLaunchMode(sp.LAUNCH_AUTO)
 
 
+def test_frame_sequences_keep_their_bits(renderer, oracle):
+    """a persistent launch learns the order of its tile rows from the frame before (row feedback): a moving camera, a change
+    of size in between (the learned order is for another number of rows: ignored), a change of scene -- every frame equals the
+    same frame rendered one wave per tile, pixels and counters"""
+    import torch
+    import bench
+    import sdf_playground_amd as sp
+
+    try:
+        for scene, config in (("labyrinth", "3"), ("cube_sea", "2")):
+            _setup(renderer, oracle, scene, 0.75)
+            renderer.setLimits(**bench.CONFIGS[config]["limits"])
+            for k in range(6):
+                w, h = ((1920, 1080), (1920, 1080), (648, 360), (1920, 1080), (1000, 562), (1920, 1080))[k]
+                cam, stime = bench.make_camera(k, w, h, config)
+                renderer.setParameters(stime)
+                got = {}
+                for mode in (sp.LAUNCH_PERSISTENT, sp.LAUNCH_PER_TILE):
+                    renderer.setLaunchMode(mode)
+                    img = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+                    renderer.render(cam, w, h, out=img)
+                    s = renderer.getStats()
+                    got[mode] = (img, (s.pixels, s.rays, s.march_evals, s.hits))
+                assert got[sp.LAUNCH_PERSISTENT][1] == got[sp.LAUNCH_PER_TILE][1] and got[sp.LAUNCH_PER_TILE][1][0] == w * h, (scene, k)
+                assert torch.equal(got[sp.LAUNCH_PERSISTENT][0].view(torch.int32), got[sp.LAUNCH_PER_TILE][0].view(torch.int32)), (scene, k)
+    finally:
+        renderer.setLaunchMode(sp.LAUNCH_AUTO)
+
+
 def test_registered_host_target(renderer, oracle):
     """sdfr_register_host_target: a page-locked host image is filled with the same bits, frame after frame; after
     unregistering, ordinary host destinations still work"""
