@@ -640,15 +640,32 @@ struct SceneGems
 		float plane3 = sd_plane(q - V3(0.f, 0.13f, 0.f), V3(0.f, 1.f, 0.f));
 		return op_smax2_c(op_smax2_c(plane1, plane2, 0.001f, 1.0f / 0.001f), plane3, 0.001f, 1.0f / 0.001f);
 	}
+	// A lower bound of gems() that needs neither of its two angular folds (an atan2, a sincos and a division each: 200 of
+	// the 260 instructions of an evaluation).  The folds keep lengths and turn the point into a sector of +-pi/8 about
+	// the local x axis, so q.x >= 0.92 rho >= 0, with rho the horizontal distance from the nearest gem's axis, itself
+	// >= |r - 1| (the axes stand on the circle of radius 1, r = distance from the scene's axis).  gems() is a smooth
+	// maximum of three planes and never below any of them:
+	//   plane3 = p.y - 1.13;   plane2 = 0.707 (q.x - q.y) >= 0.707 (1 - p.y);
+	//   max(plane1, plane2) >= (plane1 + plane2) / 2 = 0.707 (q.x - 0.1) >= 0.65 |r - 1| - 0.0707.
+	// 0.01 of slack for rounding.  Where the bound is not below the floor's distance the gems cannot be the minimum: a ray
+	// creeping away from the floor it started on (a dozen steps of every shadow ray towards the eight lights), anything
+	// high above or far from the ring.  Checked numerically in tests/test_scene_bounds_cpu.py.
+	static SDF_HD float gems_lower_bound(vec3 p)
+	{
+		const float r = length(V2(p.x, p.z));
+		return max1(max1(p.y - 1.13f, 0.707f * (1.f - p.y)), 0.65f * abs1(r - 1.f) - 0.0707f) - 0.01f;
+	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
+		if (gems_lower_bound(p) >= d) return d;
 		float idx;
 		return min1(d, gems(U, p, &idx));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
 		ground_material(sp, m);
+		if (gems_lower_bound(sp.pos) >= 2.f * SDFR_DIST_EPS) return; // not on a gem
 		float idx;
 		if (on_surface(gems(U, sp.pos, &idx)))
 		{

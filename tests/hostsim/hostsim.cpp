@@ -273,6 +273,44 @@ extern "C" long long hostsim_check_terrain_octave_skip(long long n, unsigned see
 	return bad;
 }
 
+// the gems scene's lower bound of the ring of gems (sdfr_scenes.h): never above gems(), at any time of its rotation
+extern "C" long long hostsim_check_gems_bound(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 777ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	FrameU U;
+	frame_defaults(U);
+	for (long long i = 0; i < n; ++i)
+	{
+		if (i % 1000 == 0)
+		{
+			U.stime = rnd() * 60.f;
+			SceneGems::prepare(U);
+		}
+		// around the ring, on its surfaces' scale, and far away
+		const float span = (i % 3 == 0) ? 0.4f : ((i % 3 == 1) ? 2.5f : 40.f);
+		vec3 p = V3((rnd() * 2.f - 1.f) * span, 1.f + (rnd() * 2.f - 1.f) * span, (rnd() * 2.f - 1.f) * span);
+		if (i % 3 == 0)
+		{
+			const float a = rnd() * 6.2831853f;
+			p.x += cosf(a);
+			p.z += sinf(a);
+		}
+		float idx;
+		const float g = SceneGems::gems(U, p, &idx);
+		const float lb = SceneGems::gems_lower_bound(p);
+		if (!(lb <= g)) ++bad;
+		if ((double)g - (double)lb < slack) slack = (double)g - (double)lb;
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
 // the tree scene's lattice (sdfr_scenes4.h): border_lower_bound() never exceeds lattice_border(), whatever the
 // position (small, large, on cell borders) and the direction (unit, axis-parallel, degenerate)
 extern "C" long long hostsim_check_tree_border_bound(long long n, unsigned seed, double *min_slack)

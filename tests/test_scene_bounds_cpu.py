@@ -198,3 +198,24 @@ def test_cube_sea_escape_rule_changes_no_pixel(oracle):
         assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
         saved += int(rst[..., 1].sum()) - int(st[..., 1].sum())
     assert saved > 0
+
+
+def test_gems_bound_holds_and_culling_is_invisible(oracle):
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_gems_bound.restype = ctypes.c_longlong
+    L.hostsim_check_gems_bound.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_gems_bound(6000000, 31, ctypes.byref(slack)) == 0
+    assert slack.value > 0.005  # the 0.01 of slack is not eaten by rounding
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    views = [((2.5, 2.0, 0.3), (0.0, 1.0, 0.0)), ((0.2, 0.05, 0.1), (1.0, 1.0, 0.2)), ((1.05, 1.4, 0.0), (1.0, 0.0, 0.05)), ((0.0, 6.0, 0.01), (0.0, 1.0, 0.0)),
+             ((1.4, 1.05, 0.2), (0.6, 1.0, -0.3))]
+    for k, (eye, at) in enumerate(views):
+        f = oracle.default_frame("gems", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.7 * k)
+        f.max_cost_default, f.extension_lights = 9, 7
+        ref, rst, _ = oracle.render("gems", f, stats=True)
+        img, st = hostsim.render("gems", hostsim.frame_from_oracle(f))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
+        assert np.array_equal(st, rst)
