@@ -249,12 +249,25 @@ struct SceneDistortion
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
-	struct RayInv { GroundInv ground; };
+	struct RayInv { GroundInv ground; bool rising; };
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
+		r.rising = dir.y >= 0.f;
 		return r;
+	}
+	// The displaced wall stays within 0.026 of its box (wall_lower_bound below): the box of half size (1, 1, 0.1) about
+	// (0, 1.5, 0) lies in the ball of radius 1.418 about its centre, the wall in the one of radius 1.45, below y = 2.53.
+	// A ray that does not descend (the floor is behind it) and is above that height, or whose line passes that ball at a
+	// distance or has it behind, has nothing left to hit.
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
+	{
+		if (!R.rising) return false;
+		if (p.y > 2.6f) return true;
+		const vec3 v = p - V3(0.f, 1.5f, 0.f);
+		const float b = dot(v, dir), vv = dot(v, v);
+		return vv > 1.5f * 1.5f && (b >= 0.f || vv - b * b > 1.5f * 1.5f);
 	}
 	// displace a distance field by a height function with known Lipschitz bound
 	static SDF_HD float distort(float obj, float val, float lip, float h)

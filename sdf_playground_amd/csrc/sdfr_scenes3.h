@@ -231,7 +231,14 @@ struct SceneTerrain
 	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &) { RayInv r; r.rising = dir.y >= 0.f; return r; }
 	// shape() = max(terrain, box of half size 5 about the origin) >= the box's distance >= p.y - 5: nothing above y = 5,
 	// and this scene has no other object (no floor either)
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 5.01f; }
+	// The scene has no floor: a ray whose line passes the box's circumscribed ball (radius sqrt(75) = 8.66 about the origin;
+	// 8.7) at a distance, or has it behind, is gone whichever way it points.
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
+	{
+		if (R.rising && p.y > 5.01f) return true;
+		const float b = dot(p, dir), vv = dot(p, p);
+		return vv > 8.7f * 8.7f && (b >= 0.f || vv - b * b > 8.7f * 8.7f);
+	}
 	static SDF_HD float lattice_noise(vec3 p) { return frac1(sin1(dot(p, V3(12.9898f, 78.233f, 34.531247f))) * 43758.5453f); }
 	static SDF_HD float corner_sphere(vec3 cell, vec3 p, vec3 off)
 	{
