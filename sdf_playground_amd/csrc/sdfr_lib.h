@@ -106,6 +106,19 @@ SDF_HD float sd_box(vec3 p, vec3 half_size)
 
 SDF_HD float sd_plane(vec3 p, vec3 n) { return dot(p, n); }
 
+// For Scene::ray_escapes of a scene that is a floor at y = 0 plus objects inside the ball (c, radius) and below `top`:
+// a ray that does not descend has the floor behind it, and leaves the objects behind for good once it is above `top`,
+// or if its line passes the ball at more than the radius, or if the ball lies behind it.  `radius` and `top` carry the
+// caller's slack (the direction is a unit vector to 1e-7 only).
+SDF_HD bool ray_leaves_floor_and_ball(vec3 p, vec3 dir, float top, vec3 c, float radius)
+{
+	if (!(dir.y >= 0.f)) return false;
+	if (p.y > top) return true;
+	const vec3 v = p - c;
+	const float b = dot(v, dir), vv = dot(v, v);
+	return vv > radius * radius && (b >= 0.f || vv - b * b > radius * radius);
+}
+
 // distance along the ray when `fast` (sdf_primitives.hlsl:59-70)
 SDF_HD float sd_plane_fast(vec3 p, vec3 dir, bool fast, vec3 n)
 {

@@ -34,6 +34,8 @@ struct SceneFastSphere
 		r.ground = ground_setup(dir);
 		return r;
 	}
+	// floor + one sphere of radius 0.5 about (0, 1, 0)
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.51f, V3(0.f, 1.f, 0.f), 0.52f); }
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -332,16 +334,7 @@ struct SceneFractal
 		return r;
 	}
 	// every box lies in the unit ball about (0, 1, 0) (see dist): nothing above y = 2, and the floor is behind a ray that does not descend
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
-	{
-		if (!R.rising) return false;
-		if (p.y > 2.01f) return true;
-		// ... or the line of the ray passes the ball at more than its radius (1.02: slack for a direction that is a unit
-		// vector to 1e-7 only), or the ball lies behind
-		const vec3 v = p - V3(0.f, 1.f, 0.f);
-		const float b = dot(v, dir), vv = dot(v, v);
-		return vv > 1.02f * 1.02f && (b >= 0.f || vv - b * b > 1.02f * 1.02f);
-	}
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
 	// 8-level recursive fold; returns the distance, and the level that first touched
 	static SDF_HD float fold(vec3 p, float *level_hit)
 	{
@@ -638,14 +631,7 @@ struct SceneGems
 	// ... or its line passes the ring at a distance: a gem reaches 0.13 / 0.92 = 0.141 from its axis (plane2 and plane3 give
 	// q.x <= q.y <= 0.13, the folds q.x >= 0.92 rho) and stands between y = 1 and 1.13 (plane2 with q.x >= 0: q.y >= 0), so
 	// the ring lies in the ball about (0, 1.065, 0) of radius sqrt(1.141^2 + 0.065^2) = 1.143 (1.17: slack).
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
-	{
-		if (!R.rising) return false;
-		if (p.y > 1.14f) return true;
-		const vec3 v = p - V3(0.f, 1.065f, 0.f);
-		const float b = dot(v, dir), vv = dot(v, v);
-		return vv > 1.17f * 1.17f && (b >= 0.f || vv - b * b > 1.17f * 1.17f);
-	}
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.14f, V3(0.f, 1.065f, 0.f), 1.17f); }
 	static SDF_HD float gems(const FrameU &U, vec3 p, float *ring_index)
 	{
 		vec2 xz = rot2(V2(p.x, p.z), U.su[SU_ROT_S], U.su[SU_ROT_C]);

@@ -33,6 +33,13 @@ struct SceneCube
 		const vec3 c = V3(U.scene_var[V_X], U.scene_var[V_Y], U.scene_var[V_Z]);
 		return sd_box(p - V3(0.f, 1.f, 0.f) - c, V3s(U.scene_var[V_SIZE]));
 	}
+	// floor + one box of half size `size` about (x, 1 + y, z): inside the ball of radius sqrt(3) size about its centre
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir)
+	{
+		const float size = abs1(U.scene_var[V_SIZE]);
+		const vec3 c = V3(U.scene_var[V_X], 1.f + U.scene_var[V_Y], U.scene_var[V_Z]);
+		return ray_leaves_floor_and_ball(p, dir, c.y + size * 1.001f + 0.01f, c, size * 1.7330f + 0.02f);
+	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -261,14 +268,7 @@ struct SceneDistortion
 	// (0, 1.5, 0) lies in the ball of radius 1.418 about its centre, the wall in the one of radius 1.45, below y = 2.53.
 	// A ray that does not descend (the floor is behind it) and is above that height, or whose line passes that ball at a
 	// distance or has it behind, has nothing left to hit.
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
-	{
-		if (!R.rising) return false;
-		if (p.y > 2.6f) return true;
-		const vec3 v = p - V3(0.f, 1.5f, 0.f);
-		const float b = dot(v, dir), vv = dot(v, v);
-		return vv > 1.5f * 1.5f && (b >= 0.f || vv - b * b > 1.5f * 1.5f);
-	}
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.6f, V3(0.f, 1.5f, 0.f), 1.5f); }
 	// displace a distance field by a height function with known Lipschitz bound
 	static SDF_HD float distort(float obj, float val, float lip, float h)
 	{
@@ -437,6 +437,10 @@ struct SceneSierpinski
 		}
 		return length(p) / pow1(scale, 10.f) - 0.002f;
 	}
+	// Each fold doubles the distance from the chosen vertex, and the vertices lie within 1 of the origin: |2 p - c| >=
+	// 2 |p| - 1, so |p_k| - 1 >= 2^k (|p| - 1) and tetra(p) >= |p| - 1.001: the gasket lies in the ball of radius 1.001
+	// about (0, 1, 0), below y = 2.001.
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
