@@ -112,6 +112,9 @@ struct SceneBasicTransparency
 		r.skip3 = f.has_transparent && pane(f.last_transparent_pos, 1.f) < SDFR_DIST_EPS;
 		return r;
 	}
+	// floor + three panes of half size (1, 1, 0.1) about (0, 2, -1 / 0 / 1): below y = 3, inside the ball of radius
+	// sqrt(1 + 1 + 1.1^2) = 1.79 about (0, 2, 0)
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 3.01f, V3(0.f, 2.f, 0.f), 1.82f); }
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -210,6 +213,8 @@ struct SceneCoordinateMaterial
 		const float box = sd_box(p - V3(-1.f, 3.f + U.scene_var[0], -1.f), V3s(1.f));
 		return max1(sphere, -box);
 	}
+	// floor + a sphere of radius 2 about (0, 2, 0) with a box cut out of it (max(sphere, -box) >= sphere)
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 4.01f, V3(0.f, 2.f, 0.f), 2.02f); }
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -369,6 +374,10 @@ struct SceneTable
 		o.vase = max1(max1(body, cut_top), -body - 0.01f);
 		return o;
 	}
+	// Legs (|x|, |z| = 1 +- 0.05, up to y = 1.1, down to -0.3), plate (half size 1.2 rounded by 0.025, about y = 1.125) and vase
+	// (within 0.22 of the axis, cut off at y = 1.715: vase >= cut_top) lie below y = 1.72 and in the ball of radius 1.80
+	// about (0, 0.7, 0) (plate corner and leg foot are its farthest points).
+	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.73f, V3(0.f, 0.7f, 0.f), 1.85f); }
 	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));

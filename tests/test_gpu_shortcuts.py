@@ -67,6 +67,7 @@ def test_cube_sea_shortcuts_change_no_pixel(renderer, oracle, view):
 @pytest.mark.parametrize("scene,limits", [("labyrinth", dict(iter_count=256)), ("labyrinth", dict(extension_marble_reflection=0.25)),
                                           ("fractal", dict(iter_count=512)), ("gems", dict(max_cost_default=9, extension_lights=7)),
                                           ("tree", None), ("terrain", None), ("distortion", None), ("fast_sphere", None), ("cube", None), ("sierpinski", None),
+                                          ("basic_transparency", None), ("coordinate_material", None), ("table", None),
                                           ("cube_sea", dict(max_cost_default=6))])
 def test_scenes_with_an_escape_rule(renderer, oracle, scene, limits):
     """every scene that declares ray_escapes(), at the parity tests' camera and from three more (looking up from the
