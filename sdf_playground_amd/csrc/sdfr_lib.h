@@ -110,9 +110,13 @@ SDF_HD float sd_plane(vec3 p, vec3 n) { return dot(p, n); }
 // a ray that does not descend has the floor behind it, and leaves the objects behind for good once it is above `top`,
 // or if its line passes the ball at more than the radius, or if the ball lies behind it.  `radius` and `top` carry the
 // caller's slack (the direction is a unit vector to 1e-7 only).
+// "Behind it" needs the ray to be ABOVE the floor: the fast plane of a ray that does not descend is p.y / 1e-20
+// (ground_dist), which for p.y <= 0 -- a camera under or on the floor, a child ray pushed below it -- is <= 0: the
+// reference books a HIT of the floor at that very sample.  From p.y > 1e-20 on the floor's distance is >= 1 here and
+// grows with every step of a ray that does not descend (NaN fails the test as well).
 SDF_HD bool ray_leaves_floor_and_ball(vec3 p, vec3 dir, float top, vec3 c, float radius)
 {
-	if (!(dir.y >= 0.f)) return false;
+	if (!(dir.y >= 0.f) || !(p.y > 1e-20f)) return false;
 	if (p.y > top) return true;
 	const vec3 v = p - c;
 	const float b = dot(v, dir), vv = dot(v, v);

@@ -59,6 +59,8 @@ extern "C" int hostsim_render(const char *scene, FrameU *frame, float *out_rgba,
 	return 0;
 }
 
+extern "C" int hostsim_scene_count() { return SDFR_PUBLIC_SCENE_COUNT; }
+extern "C" const char *hostsim_scene_name(int i) { return scene_name(i); }
 extern "C" int hostsim_frame_size() { return (int)sizeof(FrameU); }
 extern "C" void hostsim_frame_defaults(FrameU *f) { frame_defaults(*f); }
 

@@ -70,13 +70,16 @@ def test_cube_sea_shortcuts_change_no_pixel(renderer, oracle, view):
                                           ("basic_transparency", None), ("coordinate_material", None), ("table", None),
                                           ("cube_sea", dict(max_cost_default=6))])
 def test_scenes_with_an_escape_rule(renderer, oracle, scene, limits):
-    """every scene that declares ray_escapes(), at the parity tests' camera and from three more (looking up from the
-    floor, down from above, along the horizon): shortcuts on changes no pixel, ray or hit count and adds no step"""
+    """every scene that declares ray_escapes(), at the parity tests' camera and from six more (looking up from the
+    floor, down from above, along the horizon, from under / on / a hair above the floor): shortcuts on changes no pixel, ray or hit count and adds no step"""
     import sdf_playground_amd as sp
 
     try:
         f = _setup(renderer, oracle, scene, 0.75, limits=limits)
-        views = [None, ((0.4, 0.3, 0.3), (3.0, 4.0, 2.0)), ((1.0, 12.0, 1.0), (1.3, 0.0, 1.2)), ((-6.0, 2.3, -5.0), (6.0, 2.5, 7.0))]
+        # ... and from under the floor, exactly on it and a hair above it (round-2 review: rules that take the floor to be
+        # behind a rising ray must know that the ray is above it -- tests/test_shortcuts_cpu.py)
+        views = [None, ((0.4, 0.3, 0.3), (3.0, 4.0, 2.0)), ((1.0, 12.0, 1.0), (1.3, 0.0, 1.2)), ((-6.0, 2.3, -5.0), (6.0, 2.5, 7.0)),
+                 ((3.0, -1.0, -5.0), (0.0, 1.0, 0.0)), ((2.0, 0.0, -3.0), (0.0, 1.0, 0.0)), ((-4.0, 1e-22, 1.0), (0.0, 0.6, 0.0))]
         fovy = np.float32(sp.to_radian(60.0))
         for view in views:
             if view is not None:

@@ -34,6 +34,8 @@ def run(cases, seed, size, scenes=None, verbose=False):
             tgt = (float(rng.uniform(-2, 2)), float(rng.uniform(0, 3)), float(rng.uniform(-2, 2)))
             if c % 5 == 4:  # sometimes from far away / from below the canopy / grazing the floor
                 eye = (float(rng.uniform(-40, 40)), float(rng.choice([0.05, 0.5, 25.0])), float(rng.uniform(-40, 40)))
+            if c % 7 == 6:  # under the floor, exactly on it, a hair above it (the fast plane divides the height by 1e-20)
+                eye = (eye[0], float(rng.choice([-1.0, -0.05, 0.0, 1e-22, 1e-6])), eye[2])
             stime = float(np.float32(rng.uniform(0, 30)))
             basis = po.camera_lookat(eye, tgt, fovy, asp)
             f = po.default_frame(scene, W, H, basis=basis, stime=stime)
