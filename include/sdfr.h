@@ -53,7 +53,9 @@ int sdfr_scene_count(void);
 const char *sdfr_scene_name(int index);
 /* besides the listed names: "debug_materials", the library's own diagnostic scene (four objects wearing
  * the driver's MATERIAL_ITER / PLAIN / NORMAL1 / NORMAL2 views, pshader_sdf.hlsl:430-455, which no
- * reference scene emits; not part of the reference's scene list, hence not counted above) */
+ * reference scene emits; not part of the reference's scene list, hence not counted above), and "normal_test",
+ * a scene with a map_normal callback (sdf_structs.hlsl:39-52: its own normal on one object, a wider
+ * normal_sample_dist -- rounded corners -- on two others), which every scene of the reference leaves empty */
 int sdfr_load_scene(sdfr_renderer *r, const char *name);
 const char *sdfr_current_scene(const sdfr_renderer *r);
 /* Compile a scene from source text at run time -- the reference's edit-and-reload workflow
@@ -112,6 +114,17 @@ typedef struct sdfr_limits
 	 * The reference's labyrinth has no reflective material; BASELINE configs[2] is worded "2 reflection bounces":
 	 * with 0.25 and the default cost rule (a reflection costs 3 of max_cost 7) a ray is reflected at most twice. */
 	float extension_marble_reflection;
+	/* the driver's five epsilons, `static const float` in the reference (pshader_sdf.hlsl:31-35), as run-time values.
+	 * Defaults = the reference's; anything else is a labelled EXTENSION.
+	 *   dist_eps    1e-4  "how close to the object before terminating": the march's hit test (:211), the MATERIAL and
+	 *                     OBJECT_TRANSPARENT macros (:80-81), sdSphereFast (sdf_primitives.hlsl:31), the directional
+	 *                     light's normalisation (:535); 0 < dist_eps <= 1e-3 (the built-in scenes' culling bounds and
+	 *                     escape rules are proved with 0.01 of slack)
+	 *   grad_eps    1e-4  spacing of the forward-difference normal samples (:323) -- unless the scene's map_normal sets
+	 *                     its own normal_sample_dist; > 0
+	 *   reflect_eps 1e-3, refract_eps 1e-3  how far a reflected / refracted ray starts along its direction (:373,397,411); >= 0
+	 *   shadow_eps  3e-4  shadow rays start max(shadow_eps, normal_sample_dist) off the surface (:520); >= 0 */
+	float dist_eps, grad_eps, reflect_eps, refract_eps, shadow_eps;
 } sdfr_limits;
 int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out);
 int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *limits);

@@ -44,6 +44,7 @@ struct orc_frame
 	float scene_var[8];
 	int extension_lights; // 0..7, extension (SURVEY.md 8d cfg 5)
 	float extension_marble_reflection; // 0 = reference, extension (SURVEY.md 8d cfg 3 as worded)
+	float dist_eps, grad_eps, reflect_eps, refract_eps, shadow_eps; // pshader_sdf.hlsl:31-35
 };
 
 } // extern "C"
@@ -122,6 +123,8 @@ const std::vector<SceneEntry> &test_scenes()
 {
 	static const std::vector<SceneEntry> table = {
 		{"debug_materials", "", {}, &ps_main<SceneDebugMaterials>},
+		{"normal_test", "VAR_round(min = 0.0001, max = 0.05, start = 0.01) VAR_analytic(min = 0, max = 1, step = 1, start = 1)", {"round", "analytic"},
+			&ps_main<SceneNormalTest>},
 	};
 	return table;
 }
@@ -165,6 +168,11 @@ Frame to_frame(const orc_frame &f)
 		F.scene_var[i] = f.scene_var[i];
 	F.extension_lights = f.extension_lights < 0 ? 0 : (f.extension_lights > 7 ? 7 : f.extension_lights);
 	F.extension_marble_reflection = f.extension_marble_reflection;
+	F.dist_eps = f.dist_eps;
+	F.grad_eps = f.grad_eps;
+	F.reflect_eps = f.reflect_eps;
+	F.refract_eps = f.refract_eps;
+	F.shadow_eps = f.shadow_eps;
 	return F;
 }
 
@@ -288,7 +296,15 @@ int orc_render(const char *scene, const orc_frame *frame, float *out_rgba, unsig
 	if (frame->ray_count < 1 || frame->ray_count > MAX_RAY_COUNT || frame->light_count < 0 || frame->light_count > MAX_LIGHT_COUNT ||
 		frame->width < 1 || frame->height < 1 || step_x < 1 || step_y < 1 || frame->iter_count < 1 || frame->bounce_count < 0)
 		return -2;
+	if (!(frame->dist_eps > 0.f) || !(frame->grad_eps > 0.f) || !(frame->reflect_eps >= 0.f) || !(frame->refract_eps >= 0.f) || !(frame->shadow_eps >= 0.f))
+		return -3; // a frame that was not made by default_frame
 	const Frame F = to_frame(*frame);
+	// the driver's epsilons (sdf_lib.h): set before the threads start
+	dist_eps = F.dist_eps;
+	grad_eps = F.grad_eps;
+	reflect_eps = F.reflect_eps;
+	refract_eps = F.refract_eps;
+	shadow_eps = F.shadow_eps;
 	if (nthreads < 1)
 		nthreads = 1;
 	std::atomic<int> next_row(0);

@@ -40,6 +40,11 @@ class OrcFrame(ctypes.Structure):
         ("scene_var", ctypes.c_float * 8),
         ("extension_lights", ctypes.c_int),
         ("extension_marble_reflection", ctypes.c_float),
+        ("dist_eps", ctypes.c_float),
+        ("grad_eps", ctypes.c_float),
+        ("reflect_eps", ctypes.c_float),
+        ("refract_eps", ctypes.c_float),
+        ("shadow_eps", ctypes.c_float),
     ]
 
 
@@ -160,6 +165,7 @@ def default_frame(scene, width, height, basis=None, stime=0.0):
     f.iter_count, f.bounce_count, f.ray_count, f.light_count = 100, 16, 8, 8
     f.range = 100.0
     f.max_cost_default = 7
+    f.dist_eps, f.grad_eps, f.reflect_eps, f.refract_eps, f.shadow_eps = 0.0001, 0.0001, 0.001, 0.001, 0.0003  # pshader_sdf.hlsl:31-35
     for name, _mn, _mx, start, _st, _v, slot in var_table(scene):
         if slot >= 0:
             f.scene_var[slot] = start

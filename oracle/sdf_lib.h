@@ -9,12 +9,14 @@
 
 namespace orc {
 
-// pshader_sdf.hlsl:31-36
-static const float dist_eps = 0.0001f;
-static const float grad_eps = 0.0001f;
-static const float reflect_eps = 0.001f;
-static const float refract_eps = 0.001f;
-static const float shadow_eps = 0.0003f;
+// pshader_sdf.hlsl:31-36.  The reference's five `static const float` epsilons, as variables: orc_render copies them from
+// the frame before it starts its threads (sdfr_limits exposes them as run-time values; anything but these defaults is a
+// labelled extension).  One render at a time per process -- this is test infrastructure.
+inline float dist_eps = 0.0001f;
+inline float grad_eps = 0.0001f;
+inline float reflect_eps = 0.001f;
+inline float refract_eps = 0.001f;
+inline float shadow_eps = 0.0003f;
 
 // math_constants.hlsl:4-7
 static const float sqrt_half = 0.70710678118654752f;
@@ -56,6 +58,8 @@ struct Frame
 	// EXTENSION (not in the reference; SURVEY.md 8d cfg 3 "2 reflection bounces"): the labyrinth's marble
 	// (MATERIAL_MARBLE_DARK / _LIGHT) gets this reflection_color; 0 = reference behaviour (no reflective material)
 	real extension_marble_reflection;
+	// pshader_sdf.hlsl:31-35 (reference values 1e-4, 1e-4, 1e-3, 1e-3, 3e-4; anything else is an extension)
+	float dist_eps, grad_eps, reflect_eps, refract_eps, shadow_eps;
 };
 
 // sdf_structs.hlsl:4-21

@@ -60,7 +60,10 @@ class Limits(ctypes.Structure):
 
     _fields_ = [("iter_count", ctypes.c_int), ("bounce_count", ctypes.c_int), ("ray_count", ctypes.c_int), ("light_count", ctypes.c_int),
                 ("range", ctypes.c_float), ("max_cost_default", ctypes.c_int), ("extension_lights", ctypes.c_int),
-                ("extension_marble_reflection", ctypes.c_float)]
+                ("extension_marble_reflection", ctypes.c_float),
+                # pshader_sdf.hlsl:31-35 at run time; defaults 1e-4, 1e-4, 1e-3, 1e-3, 3e-4 (anything else: extension)
+                ("dist_eps", ctypes.c_float), ("grad_eps", ctypes.c_float), ("reflect_eps", ctypes.c_float), ("refract_eps", ctypes.c_float),
+                ("shadow_eps", ctypes.c_float)]
 
 
 class Stats(ctypes.Structure):

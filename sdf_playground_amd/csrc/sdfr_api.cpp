@@ -399,6 +399,11 @@ int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out)
 	out->max_cost_default = (int)r->U.max_cost_default;
 	out->extension_lights = r->U.extension_lights;
 	out->extension_marble_reflection = r->U.extension_marble_reflection;
+	out->dist_eps = r->U.dist_eps;
+	out->grad_eps = r->U.grad_eps;
+	out->reflect_eps = r->U.reflect_eps;
+	out->refract_eps = r->U.refract_eps;
+	out->shadow_eps = r->U.shadow_eps;
 	return SDFR_OK;
 }
 
@@ -410,6 +415,9 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 		l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1 ||
 		!(l->extension_marble_reflection >= 0.f && l->extension_marble_reflection <= 1.f))
 		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
+	if (!(l->dist_eps > 0.f && l->dist_eps <= SDFR_MAX_DIST_EPS) || !(l->grad_eps > 0.f && l->grad_eps <= 1.f) || !(l->reflect_eps >= 0.f && l->reflect_eps <= 1.f) ||
+		!(l->refract_eps >= 0.f && l->refract_eps <= 1.f) || !(l->shadow_eps >= 0.f && l->shadow_eps <= 1.f))
+		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "epsilons out of range (0 < dist_eps <= 1e-3, 0 < grad_eps <= 1, 0 <= reflect_eps, refract_eps, shadow_eps <= 1)");
 	r->U.iter_count = l->iter_count;
 	r->U.bounce_count = l->bounce_count;
 	r->U.ray_count = l->ray_count;
@@ -418,6 +426,11 @@ int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 	r->U.max_cost_default = (uint32_t)l->max_cost_default;
 	r->U.extension_lights = l->extension_lights;
 	r->U.extension_marble_reflection = l->extension_marble_reflection;
+	r->U.dist_eps = l->dist_eps;
+	r->U.grad_eps = l->grad_eps;
+	r->U.reflect_eps = l->reflect_eps;
+	r->U.refract_eps = l->refract_eps;
+	r->U.shadow_eps = l->shadow_eps;
 	return SDFR_OK;
 }
 

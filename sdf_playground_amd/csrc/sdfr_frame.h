@@ -41,6 +41,10 @@ struct FrameU
 	// is booked as the miss it is going to be without marching the remaining steps.  The per-pixel count of march
 	// evaluations then falls short of the reference's; 0 = march every step (the counters equal the oracle's).
 	int step_shortcuts;
+	// the driver's five epsilons (pshader_sdf.hlsl:31-35: dist_eps 1e-4 "how close to the object before terminating" -- the
+	// hit test, the MATERIAL / OBJECT_TRANSPARENT macros, sdSphereFast, the directional light's normalisation --, grad_eps
+	// 1e-4, reflect_eps 1e-3, refract_eps 1e-3, shadow_eps 3e-4) as run-time values (sdfr_limits); defaults = reference
+	float dist_eps, grad_eps, reflect_eps, refract_eps, shadow_eps;
 };
 
 // One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct
@@ -69,6 +73,15 @@ struct SurfacePoint
 	float camera_distance;
 	vec3 right_off, bottom_off; // pixel footprint per unit of distance
 	vec3 normal;                // MaterialInput.obj_normal: the geometric normal at the hit
+};
+
+// NormalOutput of the scene ABI (sdf_structs.hlsl:39-52), preloaded by the driver (pshader_sdf.hlsl:320-323):
+// use_normal false, normal 0, sample_dist = grad_eps
+struct NormalOut
+{
+	float sample_dist; // normal_sample_dist: spacing of the forward-difference samples; "larger than usual values lead to rounded corners"
+	vec3 normal;       // the scene's own normal
+	bool use_normal;   // true: take `normal` instead of sampling
 };
 
 // MaterialOutput of the scene ABI (sdf_structs.hlsl:66-110), defaults of pshader_sdf.hlsl:338-351

@@ -18,6 +18,11 @@ inline void frame_defaults(FrameU &U)
 	U.max_cost_default = 7;
 	U.debug_scale = 0.2f;
 	U.show_objects = 1.f;
+	U.dist_eps = SDFR_DEFAULT_DIST_EPS; // pshader_sdf.hlsl:31-35
+	U.grad_eps = SDFR_DEFAULT_GRAD_EPS;
+	U.reflect_eps = SDFR_DEFAULT_REFLECT_EPS;
+	U.refract_eps = SDFR_DEFAULT_REFRACT_EPS;
+	U.shadow_eps = SDFR_DEFAULT_SHADOW_EPS;
 }
 
 inline void frame_derive(FrameU &U, int scene_index)

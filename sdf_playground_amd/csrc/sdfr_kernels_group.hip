@@ -34,7 +34,7 @@ __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void k_pixel(FrameU U, RowMap rm, uint
 // WAVEFRONT schedule (k_init lives in sdfr_kernels.hip)
 // =================================================================================================
 // march result fields
-enum { RS_STATUS = 0, RS_T, RS_D, RS_NX, RS_NY, RS_NZ, RS_COUNT };
+enum { RS_STATUS = 0, RS_T, RS_D, RS_NX, RS_NY, RS_NZ, RS_SAMPLE_DIST, RS_COUNT };
 // counters[]: [r] = size of round r's list (r = 0..16); [32 + r] = march cursor of round r
 enum { CNT_ROUND0 = 0 };
 
@@ -43,7 +43,7 @@ enum { CNT_ROUND0 = 0 };
 enum { LANE_IDLE = 0, LANE_MARCH = 1, LANE_GRAD0 = 2, LANE_GRAD1 = 3, LANE_GRAD2 = 4 };
 
 template <class Scene, bool DBG>
-__global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
+__global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, RowMap rm, WavefrontWorkspace ws, const uint32_t *__restrict__ list,
 	const uint32_t *__restrict__ n_ptr, uint32_t *cursor, uint32_t *pixel_stats, RenderTotals *totals)
 {
 	const uint32_t n = *n_ptr;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 	March m = march_begin(V3s(0.f), V3s(0.f));
 	typename Scene::RayInv R = {};
 	float inside_sign = 1.f, max_range = 0.f, baseline = 0.f, g0 = 0.f, g1 = 0.f;
+	float sample_dist = U.grad_eps; // of the hit whose normal is being sampled (the scene's map_normal may widen it)
 	uint32_t evals = 0;       // of the current ray
 	uint32_t tot_evals = 0, tot_hits = 0;
 
@@ -121,19 +122,43 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 			if (marching) march_pre(m);
 			const vec3 hp = march_pos(m);
 			vec3 p = hp;
-			if (state == LANE_GRAD0) p = grad_sample_pos(hp, 0, SDFR_GRAD_EPS);
-			if (state == LANE_GRAD1) p = grad_sample_pos(hp, 1, SDFR_GRAD_EPS);
-			if (state == LANE_GRAD2) p = grad_sample_pos(hp, 2, SDFR_GRAD_EPS);
+			if (state == LANE_GRAD0) p = grad_sample_pos(hp, 0, sample_dist);
+			if (state == LANE_GRAD1) p = grad_sample_pos(hp, 1, sample_dist);
+			if (state == LANE_GRAD2) p = grad_sample_pos(hp, 2, sample_dist);
 			const float dist = map_geometry<Scene, DBG>(U, F, R, p, m.dir, marching);
 
 			if (marching)
 			{
 				evals++;
-				const int status = march_advance(m, dist * inside_sign, max_range, (uint32_t)U.iter_count);
+				const int status = march_advance(m, dist * inside_sign, max_range, (uint32_t)U.iter_count, U.dist_eps);
 				if (status == MARCH_HIT)
 				{
 					baseline = m.d * inside_sign;
 					state = LANE_GRAD0;
+					sample_dist = U.grad_eps;
+					if (SceneNormal<Scene>::available)
+					{
+						// map_normal (pshader_sdf.hlsl:318-330): the scene's own normal ends the ray here, a changed spacing feeds the samples
+						int px, py;
+						pid_to_pixel(U, rm, pid, px, py);
+						const PixelRay pr = pixel_ray(U, px, py);
+						const NormalOut no = scene_normal<Scene>(U, march_pos(m), m.dir, m.t, pr.right_ray, pr.bottom_ray);
+						sample_dist = no.sample_dist;
+						if (no.use_normal)
+						{
+							ws.result[RS_STATUS * cap + pid] = __uint_as_float((uint32_t)MARCH_HIT << 24 | m.iter);
+							ws.result[RS_T * cap + pid] = m.t;
+							ws.result[RS_D * cap + pid] = m.d;
+							ws.result[RS_NX * cap + pid] = no.normal.x;
+							ws.result[RS_NY * cap + pid] = no.normal.y;
+							ws.result[RS_NZ * cap + pid] = no.normal.z;
+							ws.result[RS_SAMPLE_DIST * cap + pid] = sample_dist;
+							tot_evals += evals;
+							tot_hits += 1;
+							if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
+							state = LANE_IDLE;
+						}
+					}
 				}
 				else if (status == MARCH_MISS)
 				{
@@ -162,6 +187,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_march(FrameU U, WavefrontWorkspa
 				ws.result[RS_NX * cap + pid] = nrm.x;
 				ws.result[RS_NY * cap + pid] = nrm.y;
 				ws.result[RS_NZ * cap + pid] = nrm.z;
+				ws.result[RS_SAMPLE_DIST * cap + pid] = sample_dist;
 				tot_evals += evals;
 				tot_hits += 1;
 				if (pixel_stats) pixel_stats[3 * (size_t)pid + 1] += evals;
@@ -217,6 +243,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 				hit.d = ws.result[RS_D * cap + pid];
 				hit.iter = iter;
 				hit.normal = V3(ws.result[RS_NX * cap + pid], ws.result[RS_NY * cap + pid], ws.result[RS_NZ * cap + pid]);
+				hit.sample_dist = ws.result[RS_SAMPLE_DIST * cap + pid];
 				hit.pos = mad(ray.dir, hit.t, ray.pos);
 				const float max_range = ray_is_shadow(ray) ? ray.shadow_range : U.range;
 				Spawner<GlobalRayStore> q(store, depths, count, U.ray_count);
@@ -332,7 +359,7 @@ static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, in
 	for (int r = 0; r < rounds; ++r)
 	{
 		if (march_events) (void)hipEventRecord(march_events[2 * r], stream);
-		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, ws, list_cur, ws.counters + r,
+		hipLaunchKernelGGL((k_march<Scene, DBG>), dim3(march_blocks), dim3(SDFR_BLOCK), 0, stream, U, rm, ws, list_cur, ws.counters + r,
 			ws.counters + 32 + r, pixel_stats, totals);
 		if (march_events) (void)hipEventRecord(march_events[2 * r + 1], stream);
 		if (shade_events) (void)hipEventRecord(shade_events[2 * r], stream);

@@ -14,13 +14,16 @@
 
 namespace sdfr {
 
-// epsilons of the reference driver (pshader_sdf.hlsl:31-35)
-#define SDFR_DIST_EPS 0.0001f
+// epsilons of the reference driver (pshader_sdf.hlsl:31-35): the defaults of FrameU::dist_eps ... shadow_eps, which is what
+// the code reads (run-time values since round 3, sdfr_limits)
+#define SDFR_DEFAULT_DIST_EPS 0.0001f
+#define SDFR_DEFAULT_GRAD_EPS 0.0001f
+#define SDFR_DEFAULT_REFLECT_EPS 0.001f
+#define SDFR_DEFAULT_REFRACT_EPS 0.001f
+#define SDFR_DEFAULT_SHADOW_EPS 0.0003f
+// the largest dist_eps sdfr_set_limits accepts: the scenes' culling bounds and escape rules carry 0.01 of slack
+#define SDFR_MAX_DIST_EPS 0.001f
 #define SDFR_MAX_WAVES_PER_BLOCK 4 // of any kernel that evaluates scenes (checked where the block sizes are defined): per-wave LDS of scene code
-#define SDFR_GRAD_EPS 0.0001f
-#define SDFR_REFLECT_EPS 0.001f
-#define SDFR_REFRACT_EPS 0.001f
-#define SDFR_SHADOW_EPS 0.0003f
 
 #define SDFR_SQRT_HALF 0.70710678118654752f
 #define SDFR_SQRT_TWO 1.41421356237309504f
@@ -34,7 +37,8 @@ enum MaterialId
 	MAT_WOOD = 20, MAT_MARBLE_DARK = 21, MAT_MARBLE_LIGHT = 22, MAT_FIRE = 23
 };
 
-SDF_HD bool on_surface(float d) { return abs1(d) < SDFR_DIST_EPS; }
+// the MATERIAL macro (pshader_sdf.hlsl:81)
+SDF_HD bool on_surface(const FrameU &U, float d) { return abs1(d) < U.dist_eps; }
 
 // ---- values a whole wave needs alike, computed once --------------------------------------------
 // Scene functions that hash the corners / neighbours of the lattice cell a point lies in do the same n independent
@@ -84,7 +88,7 @@ struct WaveShare
 SDF_HD float sd_sphere(vec3 p, float r) { return length(p) - r; }
 
 // analytic ray/sphere distance when `fast`, exact SDF otherwise (sdf_primitives.hlsl:11-45)
-SDF_HD float sd_sphere_fast(vec3 p, vec3 dir, bool fast, float r)
+SDF_HD float sd_sphere_fast(vec3 p, vec3 dir, bool fast, float r, float dist_eps)
 {
 	if (!fast) return sd_sphere(p, r);
 	float b = -dot(p, dir);
@@ -94,7 +98,7 @@ SDF_HD float sd_sphere_fast(vec3 p, vec3 dir, bool fast, float r)
 	float root = sqrt1(disc);
 	float t1 = b - root;
 	float t2 = b + root;
-	if (t1 < -SDFR_DIST_EPS) return t2 > 0.f ? t2 : 1e10f;
+	if (t1 < -dist_eps) return t2 > 0.f ? t2 : 1e10f;
 	return t1;
 }
 
@@ -505,9 +509,9 @@ SDF_HD float ground_dist(vec3 p, bool fast, const GroundInv &g)
 	float d = dot(p, V3(0.f, 1.f, 0.f));
 	return fast ? div_c(d, g.denom, g.rdenom) : d;
 }
-SDF_HD void ground_material(const SurfacePoint &sp, Material &m)
+SDF_HD void ground_material(const FrameU &U, const SurfacePoint &sp, Material &m)
 {
-	if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f))))
+	if (on_surface(U, dot(sp.pos, V3(0.f, 1.f, 0.f))))
 	{
 		vec3 off_right = sp.right_off * sp.camera_distance;
 		vec3 off_bottom = sp.bottom_off * sp.camera_distance;

@@ -16,10 +16,10 @@ namespace sdfr {
 	X(7, SceneCube) X(8, SceneGyroid) X(9, SceneBasicTransparency) X(10, SceneBasicClouds) X(11, SceneCoordinateMaterial) \
 	X(12, SceneDistortion) X(13, SceneTable) X(14, SceneSierpinski) X(15, SceneNeon) \
 	X(16, SceneFractal2) X(17, SceneShell) X(18, SceneSpiral) X(19, SceneTerrain) X(20, SceneTiling) X(21, SceneTree) \
-	X(22, SceneDebugMaterials)
+	X(22, SceneDebugMaterials) X(23, SceneNormalTest)
 // the first SDFR_PUBLIC_SCENE_COUNT are the reference's scenes (what sdfr_scene_count / sdfr_scene_name list);
 // the rest are the library's own diagnostic scenes, loaded by name only (sdfr_scene_debug.h)
-enum { SDFR_PUBLIC_SCENE_COUNT = 22, SDFR_SCENE_COUNT = 23 };
+enum { SDFR_PUBLIC_SCENE_COUNT = 22, SDFR_SCENE_COUNT = 24 };
 // the per-scene kernels are compiled in SDFR_GROUPS translation units (sdfr_kernels_group.hip): scene i in group i % SDFR_GROUPS
 #define SDFR_GROUPS 8
 #define SDFR_FOR_EACH_GROUP(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)

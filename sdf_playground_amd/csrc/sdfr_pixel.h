@@ -149,7 +149,7 @@ SDF_HD March march_begin(vec3 start, vec3 dir)
 SDF_HD vec3 march_pos(const March &m) { return mad(m.dir, m.t, m.start); }
 
 // consume one scene-distance sample `d` taken at march_pos(m); requires m.iter < iter_count
-SDF_HD int march_advance(March &m, float d, float dist_max, uint32_t iter_count)
+SDF_HD int march_advance(March &m, float d, float dist_max, uint32_t iter_count, float dist_eps)
 {
 	// written with selects instead of branches: the loop body is short and every lane of the wave
 	// takes one of the three ways each iteration
@@ -157,7 +157,7 @@ SDF_HD int march_advance(March &m, float d, float dist_max, uint32_t iter_count)
 	// over-stepped: rewind to the last safe point and continue without relaxation
 	const bool over = (m.factor > 1.f) & ((m.last_d + d) < m.last_d * m.factor);
 	const bool out_of_range = m.t > dist_max;
-	const bool stop = !over & (out_of_range | (d < SDFR_DIST_EPS));
+	const bool stop = !over & (out_of_range | (d < dist_eps));
 	const float t_fwd = m.t + d * m.factor;
 	const float safe_fwd = m.t + d;
 	m.last_d = over ? m.last_d : d;
@@ -179,6 +179,49 @@ SDF_HD vec3 grad_sample_pos(vec3 p, int axis, float eps)
 	return p + V3(0.f, 0.f, eps);
 }
 
+// ---- the scene's map_normal (pshader_sdf.hlsl:318-330; sdf_structs.hlsl:39-52) -----------------------
+// A scene may declare `static SDF_HD void normal(const FrameU &U, const SurfacePoint &sp, NormalOut &no)`: called once per
+// hit with the NormalOutput preloaded {grad_eps, 0, false}; sp.normal is 0 (the geometric normal is what is being made).
+// It may hand back the normal itself (no.use_normal = true: the three forward-difference evaluations are not made) and /
+// or change no.sample_dist, the spacing of those samples -- which the driver uses a second time, for the offset of the
+// shadow rays (pshader_sdf.hlsl:520).  Every scene of the reference leaves map_normal empty: a scene without the
+// member costs nothing.
+template <class...>
+struct VoidOfN { typedef void type; };
+template <class Scene, class = void>
+struct SceneNormal
+{
+	static constexpr bool available = false;
+	static SDF_HD void call(const FrameU &, const SurfacePoint &, NormalOut &) {}
+};
+template <class Scene>
+struct SceneNormal<Scene, typename VoidOfN<decltype(&Scene::normal)>::type>
+{
+	static constexpr bool available = true;
+	static SDF_HD void call(const FrameU &U, const SurfacePoint &sp, NormalOut &no) { Scene::normal(U, sp, no); }
+};
+// normal_output as the driver preloads it, then the scene's say
+template <class Scene>
+SDF_HD NormalOut scene_normal(const FrameU &U, vec3 hit_pos, vec3 dir, float camera_distance, vec3 right_ray, vec3 bottom_ray)
+{
+	NormalOut no;
+	no.sample_dist = U.grad_eps;
+	no.normal = V3s(0.f);
+	no.use_normal = false;
+	if (SceneNormal<Scene>::available)
+	{
+		SurfacePoint sp;
+		sp.pos = hit_pos;
+		sp.dir = dir;
+		sp.camera_distance = camera_distance;
+		sp.right_off = right_ray;
+		sp.bottom_off = bottom_ray;
+		sp.normal = V3s(0.f);
+		SceneNormal<Scene>::call(U, sp, no);
+	}
+	return no;
+}
+
 // ---- results handed from marching to shading ---------------------------------------------------
 struct HitInfo
 {
@@ -187,6 +230,7 @@ struct HitInfo
 	float d;          // scene_distance (* inside_sign)
 	uint32_t iter;
 	vec3 normal;      // normal_output.normal
+	float sample_dist; // normal_output.normal_sample_dist: grad_eps unless the scene's map_normal changed it (pshader_sdf.hlsl:323,520)
 };
 
 // the queue storage is supplied by the caller (registers/scratch in the per-pixel kernel,
@@ -243,7 +287,7 @@ SDF_HD void map_material(const FrameU &U, const DebugFlags &F, const SurfacePoin
 	if (F.plane_on)
 	{
 		float plane = sd_plane(sp.pos - V3(U.debug_x, U.debug_y, U.debug_z), U.debug_normal);
-		on_debug_plane = on_surface(plane);
+		on_debug_plane = on_surface(U, plane);
 	}
 	if (on_debug_plane)
 	{
@@ -300,7 +344,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 		{
 			vec3 rv = reflect(view_dir, n);
 			RayRec c;
-			c.pos = mad(rv, SDFR_REFLECT_EPS, hit.pos);
+			c.pos = mad(rv, U.reflect_eps, hit.pos);
 			c.dir = rv;
 			c.contrib = m.reflection * ray.contrib;
 			c.shadow_range = 0.f;
@@ -322,7 +366,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 				rv = refract(view_dir, -n, m.ior);
 				c.bits = depth + 2;
 			}
-			c.pos = mad(rv, SDFR_REFRACT_EPS, hit.pos);
+			c.pos = mad(rv, U.refract_eps, hit.pos);
 			c.dir = rv;
 			c.contrib = m.refraction * ray.contrib;
 			c.shadow_range = 0.f;
@@ -398,7 +442,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 		if (use_light)
 		{
 			const float ambient = Scene::ambient(); // map_light may override the default 0.075
-			float move = max1(SDFR_SHADOW_EPS, SDFR_GRAD_EPS) + max1(0.f, -hit.d);
+			float move = max1(U.shadow_eps, hit.sample_dist) + max1(0.f, -hit.d);
 			vec3 lit_pos = mad(n, move, hit.pos);
 			const float alpha = sat1(m.diffuse.w);
 
@@ -422,7 +466,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 				float falloff = 1.f;
 				if (L.directional)
 				{
-					ldir = L.pos / (length(L.pos) + SDFR_DIST_EPS);
+					ldir = L.pos / (length(L.pos) + U.dist_eps);
 					trace_dist = U.range;
 				}
 				else

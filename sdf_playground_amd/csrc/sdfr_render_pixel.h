@@ -181,7 +181,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 				status = MARCH_MISS;
 				break;
 			}
-			status = march_advance(m, d, max_range, (uint32_t)U.iter_count);
+			status = march_advance(m, d, max_range, (uint32_t)U.iter_count, U.dist_eps);
 		} while (status == MARCH_CONTINUE);
 		SDFR_CLK(c1);
 		SDFR_CLK_ADD(clk_march, c0, c1);
@@ -197,13 +197,28 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			hit.d = m.d;
 			hit.iter = m.iter;
 			hit.normal = V3s(0.f);
+			hit.sample_dist = U.grad_eps;
 			if (ShadowHitsNeedNormal<Scene>::value || !ray_is_shadow(ray))
 			{
-				const float baseline = m.d * inside_sign;
-				float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-				float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-				float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, SDFR_GRAD_EPS), ray.dir, false) - baseline;
-				hit.normal = normalize(V3(g0, g1, g2));
+				// map_normal, then the sampled normal unless the scene supplied one (pshader_sdf.hlsl:318-330)
+				NormalOut no;
+				if (SceneNormal<Scene>::available)
+				{
+					const PixelRay pr = store.pixel_ray_kept();
+					no = scene_normal<Scene>(U, hit.pos, ray.dir, hit.t, pr.right_ray, pr.bottom_ray);
+				}
+				else
+					no = scene_normal<Scene>(U, hit.pos, ray.dir, hit.t, V3s(0.f), V3s(0.f));
+				hit.sample_dist = no.sample_dist;
+				hit.normal = no.normal;
+				if (!no.use_normal)
+				{
+					const float baseline = m.d * inside_sign;
+					float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, no.sample_dist), ray.dir, false) - baseline;
+					float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, no.sample_dist), ray.dir, false) - baseline;
+					float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, no.sample_dist), ray.dir, false) - baseline;
+					hit.normal = normalize(V3(g0, g1, g2));
+				}
 			}
 #ifdef SDFR_PHASE_CLOCKS
 			asm volatile("" : "+v"(hit.normal.x), "+v"(hit.normal.y), "+v"(hit.normal.z));

@@ -8,7 +8,8 @@
 //   ray_setup()   once per ray: everything in map() that depends on the ray only
 //   dist()        map(..., geometry_step = true): scene distance at a point
 //   material()    map(..., geometry_step = false): material of the surface at a hit point
-//   use_normal()  map_normal (no config scene provides one)
+//   normal()      map_normal, optional (SceneNormal, sdfr_pixel.h); every scene of the reference leaves it empty, so
+//                 none of the scenes here has one -- the diagnostic scene normal_test does (sdfr_scene_debug.h)
 //   light()       map_light, one light slot at a time
 //   background()  map_background
 //
@@ -28,29 +29,29 @@ struct SceneFastSphere
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
 		return r;
 	}
 	// floor + one sphere of radius 0.5 about (0, 1, 0)
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.51f, V3(0.f, 1.f, 0.f), 0.52f); }
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3 dir, bool fast)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.51f, V3(0.f, 1.f, 0.f), 0.52f); }
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		return min1(d, sd_sphere_fast(p - V3(0.f, 1.f, 0.f), dir, fast, 0.5f));
+		return min1(d, sd_sphere_fast(p - V3(0.f, 1.f, 0.f), dir, fast, 0.5f, U.dist_eps));
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(sd_sphere(sp.pos - V3(0.f, 1.f, 0.f), 0.5f)))
+		ground_material(U, sp, m);
+		if (on_surface(U, sd_sphere(sp.pos - V3(0.f, 1.f, 0.f), 0.5f)))
 		{
 			m.diffuse = V4(0.2f, 0.7f, 0.2f, 1.f);
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -70,7 +71,7 @@ struct SceneCubeSea
 	// tell, any divisor (tools/divsweep_long.py; the ground plane relies on the same fact).
 	// Directions closer to an axis than 2^-60, and exact zeros, keep the IEEE division.
 	struct RayInv { GroundInv ground; vec2 barrier; vec2 rdir; bool exact_x, exact_z, rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -86,7 +87,7 @@ struct SceneCubeSea
 	// and every cube below it for good: only the cell guard still stops it, once per cell wall, out to the range of 100 --
 	// two thirds of this scene's march steps (sky-bound primary and reflection rays, shadow rays towards the sun once
 	// they have cleared the cubes).
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 3.66f; }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 3.66f; }
 	static SDF_HD float guard_quotient(float num, float den, float rden, bool exact)
 	{
 		if (exact) return div_c(num, den, rden);
@@ -147,9 +148,9 @@ struct SceneCubeSea
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		Cell c = eval_cell(U, sp.pos);
-		if (on_surface(c.cube))
+		if (on_surface(U, c.cube))
 		{
 			if (c.is_other)
 			{
@@ -164,7 +165,7 @@ struct SceneCubeSea
 			}
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -183,13 +184,13 @@ struct SceneLabyrinth
 	static SDF_HD float fire_cone(vec3 p) { return sd_round_cone(p, V3(0.f, 1.1f, 0.f), V3(0.f, 1.6f, 0.f), 0.15f, 0.1f); }
 
 	struct RayInv { GroundInv ground; bool skip_fire, rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
 		// a ray continuing through a transparent surface ignores the fire it just left
 		// (OBJECT_TRANSPARENT, pshader_sdf.hlsl:80; sdf_scene_labyrinth.hlsl:55,62)
-		r.skip_fire = f.has_transparent && fire_cone(f.last_transparent_pos) < SDFR_DIST_EPS;
+		r.skip_fire = f.has_transparent && fire_cone(f.last_transparent_pos) < U.dist_eps;
 		r.rising = dir.y >= 0.f;
 		return r;
 	}
@@ -197,7 +198,7 @@ struct SceneLabyrinth
 	// lie in the ball about (5.2, 2.9, 3) of radius 0.9 (see dist).  A ray above that height that does not descend has the
 	// floor behind it as well: the sky-bound primary rays of the upper part of the picture (they start above the walls:
 	// no step at all) and every shadow ray once it has cleared the walls.
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 4.01f; }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 4.01f; }
 
 	static SDF_HD float vase(vec3 p)
 	{
@@ -261,7 +262,7 @@ struct SceneLabyrinth
 		const float k = reach + radius;
 		return dot(v, v) >= k * k;
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		const vec3 wp = fold(p);
@@ -282,35 +283,35 @@ struct SceneLabyrinth
 	// and the vase / torch only where their bounding balls (see dist) allow |distance| < 1e-4.
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		const vec3 wp = fold(sp.pos);
-		if (on_surface(walls(wp)))
+		if (on_surface(U, walls(wp)))
 		{
 			m.mpos = sp.pos;
 			m.id = MAT_MARBLE_LIGHT;
 			return;
 		}
 		const vec3 q = vase_local(wp);
-		if (!beyond(q - V3(0.f, 1.2f, 0.f), SDFR_DIST_EPS, 1.35f + 0.15f + 0.01f) && on_surface(vase(q)))
+		if (!beyond(q - V3(0.f, 1.2f, 0.f), U.dist_eps, 1.35f + 0.15f + 0.01f) && on_surface(U, vase(q)))
 		{
 			m.mpos = sp.pos * 3.f;
 			m.id = MAT_MARBLE_DARK;
 			return;
 		}
-		if (beyond(wp - V3(5.f, 2.f, 3.f) - V3(0.2f, 0.9f, 0.f), SDFR_DIST_EPS, 0.9f + 0.01f)) return;
+		if (beyond(wp - V3(5.f, 2.f, 3.f) - V3(0.2f, 0.9f, 0.f), U.dist_eps, 0.9f + 0.01f)) return;
 		const Torch t = torch(wp);
-		if (on_surface(t.wood))
+		if (on_surface(U, t.wood))
 		{
 			m.mpos = V3(sp.pos.x, sp.pos.z, sp.pos.y) * 2.f;
 			m.id = MAT_WOOD;
 		}
-		else if (on_surface(t.fire))
+		else if (on_surface(U, t.fire))
 		{
 			m.mpos = t.torch_pos * 3.f - V3(0.f, U.su[SU_FIRE_SCROLL], 0.f);
 			m.id = MAT_FIRE;
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -326,7 +327,7 @@ struct SceneFractal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; bool rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -334,7 +335,7 @@ struct SceneFractal
 		return r;
 	}
 	// every box lies in the unit ball about (0, 1, 0) (see dist): nothing above y = 2, and the floor is behind a ray that does not descend
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
 	// 8-level recursive fold; returns the distance, and the level that first touched
 	static SDF_HD float fold(vec3 p, float *level_hit)
 	{
@@ -394,16 +395,16 @@ struct SceneFractal
 		}
 		return d;
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		return fold_below(p, min1(3e38f, ground_dist(p, fast, R.ground)));
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		float lvl;
 		float d = fold(sp.pos, &lvl);
-		if (on_surface(d))
+		if (on_surface(U, d))
 		{
 			m.diffuse.x = 0.9f;
 			m.diffuse.y = 0.7f;
@@ -411,7 +412,7 @@ struct SceneFractal
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -438,7 +439,7 @@ struct SceneLense
 		U.su[SU_MIRROR_C] = sc.y;
 	}
 	struct RayInv { int unused; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
 
 	struct Objects { float bg1, bg2, lense, sphere, mirror, frame; vec3 mirror_pos; vec2 bg1_xz; };
 	static SDF_HD float blob(vec3 p)
@@ -556,7 +557,7 @@ struct SceneLense
 	{
 		Objects o = eval_objects(U, sp.pos);
 		vec2 cell_index = (V2(sp.pos.x, sp.pos.z) - o.bg1_xz) / 3.f;
-		if (on_surface(o.bg1))
+		if (on_surface(U, o.bg1))
 		{
 			vec2 a = cell_index * 0.3f;
 			vec3 c1 = V3(sin1(a.x) * 0.5f + 0.5f, sin1(a.y) * 0.5f + 0.5f, 1.f);
@@ -566,38 +567,38 @@ struct SceneLense
 			set_rgb(m.specular, 1.f);
 			m.reflection = V3s(0.5f);
 		}
-		else if (on_surface(o.bg2))
+		else if (on_surface(U, o.bg2))
 		{
 			m.diffuse = V4(1.f, 0.5f, 0.f, 1.f);
 			set_rgb(m.specular, 1.f);
 			m.reflection = V3s(0.5f);
 		}
-		else if (on_surface(o.lense))
+		else if (on_surface(U, o.lense))
 		{
 			m.diffuse = V4(0.3f, 0.3f, 0.3f, 1.f);
 			m.refraction = V3(0.9f, 0.9f, 0.9f);
 		}
-		else if (on_surface(o.sphere))
+		else if (on_surface(U, o.sphere))
 		{
 			m.diffuse = V4(1.f, 0.2f, 0.2f, 1.f);
 			m.emissive = V3(8.f, 0.f, 0.f);
 			set_rgb(m.specular, 1.f);
 			m.reflection = V3s(0.25f);
 		}
-		else if (on_surface(o.mirror))
+		else if (on_surface(U, o.mirror))
 		{
 			m.diffuse = V4(0.1f, 0.1f, 0.1f, 1.f);
 			float mix = U.scene_var[SV_MIXING];
 			m.refraction = V3s(mix);
 			m.reflection = V3s(1.f - mix);
 		}
-		else if (on_surface(o.frame))
+		else if (on_surface(U, o.frame))
 		{
 			m.mpos = o.mirror_pos;
 			m.id = MAT_WOOD;
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	// the scene carries its own copy of the sky (sdf_scene_lense.hlsl:108-117), same arithmetic
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
@@ -619,7 +620,7 @@ struct SceneGems
 		U.su[SU_ROT_C] = sc.y;
 	}
 	struct RayInv { GroundInv ground; bool rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -631,7 +632,7 @@ struct SceneGems
 	// ... or its line passes the ring at a distance: a gem reaches 0.13 / 0.92 = 0.141 from its axis (plane2 and plane3 give
 	// q.x <= q.y <= 0.13, the folds q.x >= 0.92 rho) and stands between y = 1 and 1.13 (plane2 with q.x >= 0: q.y >= 0), so
 	// the ring lies in the ball about (0, 1.065, 0) of radius sqrt(1.141^2 + 0.065^2) = 1.143 (1.17: slack).
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.14f, V3(0.f, 1.065f, 0.f), 1.17f); }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.14f, V3(0.f, 1.065f, 0.f), 1.17f); }
 	static SDF_HD float gems(const FrameU &U, vec3 p, float *ring_index)
 	{
 		vec2 xz = rot2(V2(p.x, p.z), U.su[SU_ROT_S], U.su[SU_ROT_C]);
@@ -669,10 +670,10 @@ struct SceneGems
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (gems_lower_bound(sp.pos) >= 2.f * SDFR_DIST_EPS) return; // not on a gem
+		ground_material(U, sp, m);
+		if (gems_lower_bound(sp.pos) >= 2.f * U.dist_eps) return; // not on a gem
 		float idx;
-		if (on_surface(gems(U, sp.pos, &idx)))
+		if (on_surface(U, gems(U, sp.pos, &idx)))
 		{
 			bool ruby = frac1(idx * 0.5f + 0.25f) > 0.5f;
 			m.diffuse.x = 0.8f;
@@ -682,7 +683,7 @@ struct SceneGems
 			m.refraction = V3s(0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -722,7 +723,7 @@ struct SceneLightShadows
 		}
 	}
 	struct RayInv { GroundInv ground; bool is_shadow; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -751,14 +752,14 @@ struct SceneLightShadows
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 #pragma unroll
 		for (int i = 0; i < 5; ++i)
 		{
-			if (on_surface(sphere(U, sp.pos, i)))
+			if (on_surface(U, sphere(U, sp.pos, i)))
 				m.emissive = V3(U.su[SU_COLORS + 3 * i], U.su[SU_COLORS + 3 * i + 1], U.su[SU_COLORS + 3 * i + 2]);
 		}
-		if (on_surface(cubes(sp.pos)))
+		if (on_surface(U, cubes(sp.pos)))
 		{
 			set_rgb(m.diffuse, 0.65f);
 			set_rgb(m.specular, 0.75f);

@@ -22,7 +22,7 @@ struct SceneCube
 	}
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -47,14 +47,14 @@ struct SceneCube
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(cube(U, sp.pos)))
+		ground_material(U, sp, m);
+		if (on_surface(U, cube(U, sp.pos)))
 		{
 			m.diffuse = V4(U.scene_var[V_RED], U.scene_var[V_GREEN], U.scene_var[V_BLUE], 1.f);
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -67,7 +67,7 @@ struct SceneGyroid
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { int unused; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
 	// a gyroid shell clipped to the unit cube; no floor in this scene
 	static SDF_HD float shape(vec3 p)
 	{
@@ -77,10 +77,10 @@ struct SceneGyroid
 		g = abs1(g) - 0.01f;
 		return max1(g, sd_box(p, V3(1.f, 1.f, 1.f)));
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &, vec3 p, vec3, bool) { return min1(3e38f, shape(p)); }
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool) { return min1(3e38f, shape(p)); }
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		if (on_surface(shape(sp.pos)))
+		if (on_surface(U, shape(sp.pos)))
 		{
 			m.diffuse.x = 0.9f;
 			m.diffuse.y = 0.7f;
@@ -88,7 +88,7 @@ struct SceneGyroid
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -103,19 +103,19 @@ struct SceneBasicTransparency
 	static SDF_HD float pane(vec3 p, float z) { return sd_box(p - V3(0.f, 2.f, z), V3(1.f, 1.f, 0.1f)); }
 	// a ray continuing through a pane ignores the pane it just left (OBJECT_TRANSPARENT)
 	struct RayInv { GroundInv ground; bool skip1, skip2, skip3; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
-		r.skip1 = f.has_transparent && pane(f.last_transparent_pos, -1.f) < SDFR_DIST_EPS;
-		r.skip2 = f.has_transparent && pane(f.last_transparent_pos, 0.f) < SDFR_DIST_EPS;
-		r.skip3 = f.has_transparent && pane(f.last_transparent_pos, 1.f) < SDFR_DIST_EPS;
+		r.skip1 = f.has_transparent && pane(f.last_transparent_pos, -1.f) < U.dist_eps;
+		r.skip2 = f.has_transparent && pane(f.last_transparent_pos, 0.f) < U.dist_eps;
+		r.skip3 = f.has_transparent && pane(f.last_transparent_pos, 1.f) < U.dist_eps;
 		return r;
 	}
 	// floor + three panes of half size (1, 1, 0.1) about (0, 2, -1 / 0 / 1): below y = 3, inside the ball of radius
 	// sqrt(1 + 1 + 1.1^2) = 1.79 about (0, 2, 0)
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 3.01f, V3(0.f, 2.f, 0.f), 1.82f); }
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 3.01f, V3(0.f, 2.f, 0.f), 1.82f); }
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		const float b1 = pane(p, -1.f), b2 = pane(p, 0.f), b3 = pane(p, 1.f);
@@ -124,17 +124,17 @@ struct SceneBasicTransparency
 		d = R.skip3 ? d : min1(d, b3);
 		return d;
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(pane(sp.pos, -1.f)))
+		ground_material(U, sp, m);
+		if (on_surface(U, pane(sp.pos, -1.f)))
 			m.diffuse = V4(0.9f, 0.9f, 0.f, 0.3f);
-		else if (on_surface(pane(sp.pos, 0.f)))
+		else if (on_surface(U, pane(sp.pos, 0.f)))
 			m.diffuse = V4(0.f, 0.9f, 0.9f, 0.3f);
-		else if (on_surface(pane(sp.pos, 1.f)))
+		else if (on_surface(U, pane(sp.pos, 1.f)))
 			m.diffuse = V4(0.9f, 0.f, 0.9f, 0.3f);
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -148,14 +148,14 @@ struct SceneBasicClouds
 	static SDF_HD void prepare(FrameU &) {}
 	static SDF_HD float slab(vec3 p) { return sd_box(p - V3(0.f, 5.f, 0.f), V3(2.f, 0.5f, 2.f)); }
 	struct RayInv { GroundInv ground; bool skip_cloud; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &f)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &f)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
-		r.skip_cloud = f.has_transparent && slab(f.last_transparent_pos) < SDFR_DIST_EPS;
+		r.skip_cloud = f.has_transparent && slab(f.last_transparent_pos) < U.dist_eps;
 		return r;
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		const float c = slab(p);
@@ -163,8 +163,8 @@ struct SceneBasicClouds
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(slab(sp.pos)))
+		ground_material(U, sp, m);
+		if (on_surface(U, slab(sp.pos)))
 		{
 			// density sampled at five points along the view ray
 			const vec3 cloud_pos = sp.pos - V3(0.f, 5.f, 0.f);
@@ -176,7 +176,7 @@ struct SceneBasicClouds
 			m.diffuse = V4(c, c, c, thickness);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
 	{
 		if (i != 0) return false;
 		L.pos = V3(-1.f, -4.f, 1.5f);
@@ -201,7 +201,7 @@ struct SceneCoordinateMaterial
 	}
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -214,7 +214,7 @@ struct SceneCoordinateMaterial
 		return max1(sphere, -box);
 	}
 	// floor + a sphere of radius 2 about (0, 2, 0) with a box cut out of it (max(sphere, -box) >= sphere)
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 4.01f, V3(0.f, 2.f, 0.f), 2.02f); }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 4.01f, V3(0.f, 2.f, 0.f), 2.02f); }
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -226,8 +226,8 @@ struct SceneCoordinateMaterial
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(shape(U, sp.pos)))
+		ground_material(U, sp, m);
+		if (on_surface(U, shape(U, sp.pos)))
 		{
 			vec3 pos = (sp.pos - V3(0.f, 2.f, 0.f)) * 2.f;
 			vec3 norm = sp.normal;
@@ -248,7 +248,7 @@ struct SceneCoordinateMaterial
 			m.specular.w = 100.f;
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -262,7 +262,7 @@ struct SceneDistortion
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; bool rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -273,7 +273,7 @@ struct SceneDistortion
 	// (0, 1.5, 0) lies in the ball of radius 1.418 about its centre, the wall in the one of radius 1.45, below y = 2.53.
 	// A ray that does not descend (the floor is behind it) and is above that height, or whose line passes that ball at a
 	// distance or has it behind, has nothing left to hit.
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.6f, V3(0.f, 1.5f, 0.f), 1.5f); }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.6f, V3(0.f, 1.5f, 0.f), 1.5f); }
 	// displace a distance field by a height function with known Lipschitz bound
 	static SDF_HD float distort(float obj, float val, float lip, float h)
 	{
@@ -310,7 +310,7 @@ struct SceneDistortion
 		*valid = obj >= 0.05f;
 		return (obj - 0.026f) * 0.9999f;
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		bool valid;
@@ -318,14 +318,14 @@ struct SceneDistortion
 		if (valid && lb >= d) return d;
 		return min1(d, wall(p).box);
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		bool valid;
 		const float lb = wall_lower_bound(sp.pos, &valid);
-		if (valid && lb >= 0.1f + 2.f * SDFR_DIST_EPS) return; // (box - 0.1) < eps is impossible
+		if (valid && lb >= 0.1f + 2.f * U.dist_eps) return; // (box - 0.1) < eps is impossible
 		const Wall w = wall(sp.pos);
-		if ((w.box - 0.1f) < SDFR_DIST_EPS)
+		if ((w.box - 0.1f) < U.dist_eps)
 		{
 			const vec3 brick = lerp(V3(0.5f, 0.1f, 0.1f), V3(0.8f, 0.2f, 0.2f), w.noise);
 			const vec3 c = w.val < 0.15f ? V3(0.5f, 0.5f, 0.5f) : brick;
@@ -335,7 +335,7 @@ struct SceneDistortion
 			set_rgb(m.specular, 0.125f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -348,7 +348,7 @@ struct SceneTable
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -377,8 +377,8 @@ struct SceneTable
 	// Legs (|x|, |z| = 1 +- 0.05, up to y = 1.1, down to -0.3), plate (half size 1.2 rounded by 0.025, about y = 1.125) and vase
 	// (within 0.22 of the axis, cut off at y = 1.715: vase >= cut_top) lie below y = 1.72 and in the ball of radius 1.80
 	// about (0, 0.7, 0) (plate corner and leg foot are its farthest points).
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.73f, V3(0.f, 0.7f, 0.f), 1.85f); }
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.73f, V3(0.f, 0.7f, 0.f), 1.85f); }
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		const Objects o = eval_objects(p);
@@ -386,28 +386,28 @@ struct SceneTable
 		d = min1(d, o.legs);
 		return min1(d, o.vase);
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		const Objects o = eval_objects(sp.pos);
-		if (on_surface(o.plate))
+		if (on_surface(U, o.plate))
 		{
 			const float plank = floor1((o.p.x + 1.25f) * 4.f) / 8.f;
 			m.mpos = o.p + V3(o.p.z * 0.2f, plank, 0.f);
 			m.id = MAT_WOOD;
 		}
-		else if (on_surface(o.legs))
+		else if (on_surface(U, o.legs))
 		{
 			m.mpos = V3(o.p.x, o.p.z, o.p.y);
 			m.id = MAT_WOOD;
 		}
-		else if (on_surface(o.vase))
+		else if (on_surface(U, o.vase))
 		{
 			m.mpos = o.p * 4.f;
 			m.id = MAT_MARBLE_DARK;
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -420,7 +420,7 @@ struct SceneSierpinski
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -449,16 +449,16 @@ struct SceneSierpinski
 	// Each fold doubles the distance from the chosen vertex, and the vertices lie within 1 of the origin: |2 p - c| >=
 	// 2 |p| - 1, so |p_k| - 1 >= 2^k (|p| - 1) and tetra(p) >= |p| - 1.001: the gasket lies in the ball of radius 1.001
 	// about (0, 1, 0), below y = 2.001.
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		return min1(d, tetra(p - V3(0.f, 1.f, 0.f)));
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(tetra(sp.pos - V3(0.f, 1.f, 0.f))))
+		ground_material(U, sp, m);
+		if (on_surface(U, tetra(sp.pos - V3(0.f, 1.f, 0.f))))
 		{
 			m.diffuse.x = 0.9f;
 			m.diffuse.y = 0.7f;
@@ -466,7 +466,7 @@ struct SceneSierpinski
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -490,7 +490,7 @@ struct SceneNeon
 		U.su[SU_MIRROR_C] = sc.y;
 	}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -531,9 +531,9 @@ struct SceneNeon
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		const Objects o = eval_objects(U, sp.pos);
-		if (on_surface(o.rings))
+		if (on_surface(U, o.rings))
 		{
 			const vec3 c = V3(U.scene_var[3], U.scene_var[4], U.scene_var[5]);
 			m.emissive = c;
@@ -543,12 +543,12 @@ struct SceneNeon
 			m.diffuse.z = h.z;
 			set_rgb(m.specular, 0.5f);
 		}
-		else if (on_surface(o.mirror))
+		else if (on_surface(U, o.mirror))
 		{
 			m.reflection = V3s(0.8f);
 			set_rgb(m.specular, 0.1f);
 		}
-		else if (on_surface(o.border))
+		else if (on_surface(U, o.border))
 		{
 			m.diffuse.x = 0.5f;
 			m.diffuse.y = 0.5f;
@@ -556,7 +556,7 @@ struct SceneNeon
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };

@@ -14,7 +14,7 @@ struct SceneFractal2
 	enum { SU_SLICE_SHIFT = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_SLICE_SHIFT] = U.stime * 0.5f; }
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -47,16 +47,16 @@ struct SceneFractal2
 		const float reduced = (v - lower) / range;
 		return (reduced - floor1(reduced)) * range + lower;
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		return min1(d, fold(p - V3(0.f, 1.f, 0.f)));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
+		ground_material(U, sp, m);
 		const vec3 base = sp.pos - V3(0.f, 1.f, 0.f);
-		if (on_surface(fold(base)))
+		if (on_surface(U, fold(base)))
 		{
 			// a glowing slice sweeps diagonally through the fractal
 			const float slice = dot(base, V3s(1.f));
@@ -71,7 +71,7 @@ struct SceneFractal2
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
 	{
 		if (i != 0) return false;
 		L.pos = V3(-1.f, -4.f, 2.f);
@@ -93,7 +93,7 @@ struct SceneShell
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -107,23 +107,23 @@ struct SceneShell
 		c = op_shell(c, -0.05f, 0.05f);
 		return max1(c, -sd_plane(p, V3(-1.f, 0.f, 0.f)));
 	}
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, shells(p));
 		return min1(d, ground_dist(p, fast, R.ground)); // this scene lists the floor last
 	}
-	static SDF_HD void material(const FrameU &, const SurfacePoint &sp, Material &m)
+	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		if (on_surface(shells(sp.pos)))
+		if (on_surface(U, shells(sp.pos)))
 		{
 			m.diffuse = V4(0.6f, 0.5f, 0.2f, 1.f);
 			set_rgb(m.specular, 0.5f);
 			m.reflection = V3s(0.15f);
 		}
 		else
-			ground_material(sp, m);
+			ground_material(U, sp, m);
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
 	{
 		if (!sun_light(i, L)) return false;
 		L.color = V3(1.f, 1.2f, 1.f);
@@ -161,7 +161,7 @@ struct SceneSpiral
 		U.su[SU_LENGTH] = y_top - y_bottom;
 	}
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -206,10 +206,10 @@ struct SceneSpiral
 	{
 		SurfacePoint moved = sp;
 		moved.pos = scrolled(U, sp.pos);
-		ground_material(moved, m);
-		if (on_surface(spring(U, sp.pos))) set_rgb(m.diffuse, 0.5f);
+		ground_material(U, moved, m);
+		if (on_surface(U, spring(U, sp.pos))) set_rgb(m.diffuse, 0.5f);
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -228,12 +228,12 @@ struct SceneTerrain
 		U.su[SU_ROT_C] = sc.y;
 	}
 	struct RayInv { bool rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &) { RayInv r; r.rising = dir.y >= 0.f; return r; }
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &) { RayInv r; r.rising = dir.y >= 0.f; return r; }
 	// shape() = max(terrain, box of half size 5 about the origin) >= the box's distance >= p.y - 5: nothing above y = 5,
 	// and this scene has no other object (no floor either)
 	// The scene has no floor: a ray whose line passes the box's circumscribed ball (radius sqrt(75) = 8.66 about the origin;
 	// 8.7) at a distance, or has it behind, is gone whichever way it points.
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3 dir)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)
 	{
 		if (R.rising && p.y > 5.01f) return true;
 		const float b = dot(p, dir), vv = dot(p, p);
@@ -315,7 +315,7 @@ struct SceneTerrain
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool) { return min1(3e38f, shape(U, p)); }
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		if (on_surface(shape(U, sp.pos)))
+		if (on_surface(U, shape(U, sp.pos)))
 		{
 			m.diffuse.x = 0.8f;
 			m.diffuse.y = 0.8f;
@@ -323,7 +323,7 @@ struct SceneTerrain
 			set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };
@@ -344,7 +344,7 @@ struct SceneTiling
 	enum { SU_PULSE = 0 };
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_PULSE] = U.stime * 2.f; }
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -352,7 +352,7 @@ struct SceneTiling
 	}
 	static SDF_HD float pane(vec3 p, float x) { return sd_box(p - V3(x, 4.f, 0.f), V3(1.f, 2.f, 0.05f)); }
 	static SDF_HD float cable(vec3 p) { return sd_capped_cylinder(p - V3(4.f, 4.f, 4.f), 2.f, 0.1f); }
-	static SDF_HD float dist(const FrameU &, const RayInv &R, vec3 p, vec3, bool fast)
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, pane(p, -4.f));
 		d = min1(d, pane(p, 0.f));
@@ -378,7 +378,7 @@ struct SceneTiling
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
 		const vec2 uv = V2(sp.pos.x, sp.pos.y);
-		if (on_surface(pane(sp.pos, -4.f)))
+		if (on_surface(U, pane(sp.pos, -4.f)))
 		{
 			const vec4 v = voronoi(uv * 5.f, 0.45f);
 			const vec3 c = v.w > 0.05f ? cell_color(V2(v.x, v.y)) * 1.1f : V3(0.25f, 0.25f, 0.25f);
@@ -386,18 +386,18 @@ struct SceneTiling
 			set_rgb(m.specular, 0.4f);
 			m.specular.w = 20.f;
 		}
-		else if (on_surface(pane(sp.pos, 0.f)))
+		else if (on_surface(U, pane(sp.pos, 0.f)))
 		{
 			const vec4 t = truchet_band(op_ab2uv(uv) * 3.f, U.scene_var[V_FLIP_CHANCE], U.scene_var[V_TRUCHET_WIDTH], V2(0.f, -1.f));
 			const float green = t.w < 0.f ? 0.f : sin1(t.w * 2.f * SDFR_PI * 5.f + U.su[SU_PULSE]) * 0.5f + 0.5f;
 			m.diffuse = V4(0.f, green * green, 0.f, 1.f);
 		}
-		else if (on_surface(pane(sp.pos, 4.f)))
+		else if (on_surface(U, pane(sp.pos, 4.f)))
 		{
 			const float g = weave_grey(U, op_ab2uv(uv * 5.f));
 			m.diffuse = V4(g * 0.8f, g * 0.8f, g * 0.8f, 1.f);
 		}
-		else if (on_surface(cable(sp.pos)))
+		else if (on_surface(U, cable(sp.pos)))
 		{
 			const vec3 cp = sp.pos - V3(4.f, 4.f, 4.f);
 			const float angle = atan21(cp.z, cp.x);
@@ -406,11 +406,11 @@ struct SceneTiling
 		}
 		else
 		{
-			ground_material(sp, m);
-			if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f)))) set_rgb(m.specular, 0.5f);
+			ground_material(U, sp, m);
+			if (on_surface(U, dot(sp.pos, V3(0.f, 1.f, 0.f)))) set_rgb(m.specular, 0.5f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
 	{
 		if (!sun_light(i, L)) return false;
 		L.color = V3(1.f, 1.2f, 1.f);

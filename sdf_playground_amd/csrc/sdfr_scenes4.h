@@ -18,7 +18,7 @@ struct SceneTree
 	static SDF_HD void prepare(FrameU &U) { U.su[SU_DRIFT] = U.stime / 10.f * 0.4f; }
 
 	struct RayInv { GroundInv ground; vec2 dir2; bool rising; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -28,7 +28,7 @@ struct SceneTree
 	}
 	// the scene itself looks at its trees only below the canopy's bounding plane (dist: bounding < 0.1, i.e. y < 2.1);
 	// above it the distance is min(that plane, floor), both behind a ray that does not descend
-	static SDF_HD bool ray_escapes(const FrameU &, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 2.11f; }
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3) { return R.rising && p.y > 2.11f; }
 
 	// a truncated cone standing on the origin
 	static SDF_HD float branch(vec3 p, float h2, float r1, float r2)
@@ -177,10 +177,10 @@ struct SceneTree
 
 	struct Objects { float bounding, tree, leaves, eye, pupil, noise; };
 	// `others`: what dist() takes the minimum with besides the objects (the ground), or a negative number when
-	// the caller does not look at distances above SDFR_DIST_EPS at all (material()).  The reference clamps tree
+	// the caller does not look at distances above U.dist_eps at all (material()).  The reference clamps tree
 	// and leaves to guard = border * spacing + 0.1 so that no step leaves the lattice cell; border >= 0, so
 	// guard >= 0.1, and guard is monotone in border.  Where the guard's lower bound is not below the minimum of
-	// everything else, the clamp cannot change the scene distance (nor any on_surface() test, 0.1 > SDFR_DIST_EPS)
+	// everything else, the clamp cannot change the scene distance (nor any on_surface(U, ) test, 0.1 > U.dist_eps)
 	// and the second half of the lattice -- nine normalisations and divisions, a quarter of an evaluation -- is
 	// left out: near a tree, i.e. for the steps that close in on a hit, its six gradient probes and material().
 	static SDF_HD Objects eval_objects(const FrameU &U, vec3 p, vec2 dir2, float bounding, float others)
@@ -240,14 +240,14 @@ struct SceneTree
 	{
 		const float bounding = dot(sp.pos - V3(0.f, 2.f, 0.f), V3(0.f, 1.f, 0.f));
 		const Objects o = eval_objects(U, sp.pos, V2(0.f, 0.f), bounding, -1.f);
-		if (on_surface(o.tree))
+		if (on_surface(U, o.tree))
 		{
 			m.diffuse.x = 0.5f;
 			m.diffuse.y = 0.25f;
 			m.diffuse.z = 0.1f;
 			set_rgb(m.specular, 0.15f);
 		}
-		else if (on_surface(o.leaves))
+		else if (on_surface(U, o.leaves))
 		{
 			const vec3 green = lerp(V3(0.2f, 0.9f, 0.2f), V3(0.3f, 0.5f, 0.2f), o.noise);
 			m.diffuse.x = green.x;
@@ -255,17 +255,17 @@ struct SceneTree
 			m.diffuse.z = green.z;
 			set_rgb(m.specular, 0.15f);
 		}
-		else if (on_surface(o.eye))
+		else if (on_surface(U, o.eye))
 		{
 			set_rgb(m.diffuse, 0.9f);
 			set_rgb(m.specular, 0.15f);
 		}
-		else if (on_surface(o.pupil))
+		else if (on_surface(U, o.pupil))
 		{
 			set_rgb(m.diffuse, 0.1f);
 			set_rgb(m.specular, 0.15f);
 		}
-		else if (on_surface(dot(sp.pos, V3(0.f, 1.f, 0.f))))
+		else if (on_surface(U, dot(sp.pos, V3(0.f, 1.f, 0.f))))
 		{
 			const float turb = turbulence3(sp.pos);
 			const vec3 soil = lerp(V3(218.f, 173.f, 136.f) / 255.f, V3(140.f, 90.f, 60.f) / 255.f, turb) * 0.6f;
@@ -275,7 +275,7 @@ struct SceneTree
 			set_rgb(m.specular, 0.05f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L)
+	static SDF_HD bool light(const FrameU &U, int i, Light &L)
 	{
 		if (i != 0) return false;
 		L.pos = V3(-1.f, -1.f, 1.2f);

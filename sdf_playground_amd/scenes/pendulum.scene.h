@@ -14,7 +14,7 @@ struct Scene
 	}
 
 	struct RayInv { GroundInv ground; };
-	static SDF_HD RayInv ray_setup(const FrameU &, vec3 dir, const RayFlags &)
+	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
 	{
 		RayInv r;
 		r.ground = ground_setup(dir);
@@ -54,19 +54,19 @@ struct Scene
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{
-		ground_material(sp, m);
-		if (on_surface(ball(U, sp.pos)))
+		ground_material(U, sp, m);
+		if (on_surface(U, ball(U, sp.pos)))
 		{
 			m.diffuse = V4(0.05f, 0.05f, 0.08f, 1.f);
 			set_rgb(m.specular, 1.f);
 			m.reflection = V3s(0.7f);
 		}
-		if (on_surface(rod(U, sp.pos)))
+		if (on_surface(U, rod(U, sp.pos)))
 		{
 			m.diffuse = V4(0.6f, 0.6f, 0.65f, 1.f);
 			set_rgb(m.specular, 1.f);
 		}
-		if (on_surface(gallows(sp.pos)))
+		if (on_surface(U, gallows(sp.pos)))
 		{
 			m.id = MAT_WOOD;
 			m.mpos = sp.pos * 2.f;
@@ -74,7 +74,7 @@ struct Scene
 			set_rgb(m.specular, 0.2f);
 		}
 	}
-	static SDF_HD bool light(const FrameU &, int i, Light &L) { return sun_light(i, L); }
+	static SDF_HD bool light(const FrameU &U, int i, Light &L) { return sun_light(i, L); }
 	static SDF_HD float ambient() { return 0.075f; }
 	static SDF_HD vec3 background(const FrameU &U, vec3 dir, uint32_t) { return sky_color(dir, U.sky_s, U.sky_c); }
 };

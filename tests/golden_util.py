@@ -27,4 +27,6 @@ def oracle_frame(oracle, g):
         f.eye[i], f.front[i], f.right[i], f.top[i] = b[0][i], b[1][i], b[2][i], b[3][i]
     for i in range(8):
         f.scene_var[i] = g["scene_var"][i]
+    # the fixtures were made at the reference's epsilons (pshader_sdf.hlsl:31-35)
+    f.dist_eps, f.grad_eps, f.reflect_eps, f.refract_eps, f.shadow_eps = 0.0001, 0.0001, 0.001, 0.001, 0.0003
     return f

@@ -28,6 +28,8 @@ class FrameU(ctypes.Structure):
         ("su", ctypes.c_float * 48),
         ("extension_lights", ctypes.c_int), ("ext_light", (ctypes.c_float * 6) * 7), ("extension_marble_reflection", ctypes.c_float),
         ("step_shortcuts", ctypes.c_int),
+        ("dist_eps", ctypes.c_float), ("grad_eps", ctypes.c_float), ("reflect_eps", ctypes.c_float), ("refract_eps", ctypes.c_float),
+        ("shadow_eps", ctypes.c_float),
     ]
 
 
@@ -55,7 +57,8 @@ def frame_from_oracle(of):
     f = FrameU()
     lib().hostsim_frame_defaults(ctypes.byref(f))
     for name in ("stime", "width", "height", "iter_count", "bounce_count", "ray_count", "light_count", "range", "max_cost_default",
-                 "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects", "extension_lights", "extension_marble_reflection"):
+                 "debug_nx", "debug_ny", "debug_nz", "debug_scale", "debug_x", "debug_y", "debug_z", "show_objects", "extension_lights", "extension_marble_reflection",
+                 "dist_eps", "grad_eps", "reflect_eps", "refract_eps", "shadow_eps"):
         setattr(f, name, getattr(of, name))
     for i in range(3):
         f.eye[i], f.front[i], f.right[i], f.top[i] = of.eye[i], of.front[i], of.right[i], of.top[i]

@@ -73,7 +73,7 @@ def _setup(renderer, oracle, scene, stime, limits=None, variables=None):
     # the C++ host camera must reproduce the oracle's (and the reference's) basis bit for bit
     assert np.array_equal(renderer.getCameraBasis().view(np.uint32), basis.view(np.uint32))
     renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0,
-                       extension_marble_reflection=0.0)
+                       extension_marble_reflection=0.0, dist_eps=0.0001, grad_eps=0.0001, reflect_eps=0.001, refract_eps=0.001, shadow_eps=0.0003)
     if limits:
         renderer.setLimits(**limits)
         for k, v in limits.items():

@@ -43,6 +43,13 @@ def run(cases, seed, size, scenes=None, verbose=False):
                           ray_count=int(rng.choice([8, 8, 3])), bounce_count=int(rng.choice([16, 16, 5])),
                           light_count=8, range=100.0, extension_lights=int(rng.choice([0, 0, 0, 7])),
                           extension_marble_reflection=float(rng.choice([0.0, 0.0, 0.0, 0.25])))
+            # the driver's epsilons: the reference's, or (one case in four) all five somewhere in their accepted ranges
+            if rng.random() < 0.25:
+                limits.update(dist_eps=float(np.float32(rng.choice([1e-5, 3e-4, 1e-3]))), grad_eps=float(np.float32(rng.choice([1e-5, 1e-3, 2e-2]))),
+                              reflect_eps=float(np.float32(rng.choice([0.0, 1e-4, 1e-2]))), refract_eps=float(np.float32(rng.choice([0.0, 1e-4, 1e-2]))),
+                              shadow_eps=float(np.float32(rng.choice([0.0, 1e-4, 5e-3]))))
+            else:
+                limits.update(dist_eps=0.0001, grad_eps=0.0001, reflect_eps=0.001, refract_eps=0.001, shadow_eps=0.0003)
             for k, v in limits.items():
                 setattr(f, k, v)
             r.setLimits(**limits)
