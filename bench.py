@@ -786,29 +786,46 @@ def run(a, world):
         print(json.dumps(out), flush=True)
 
     if distributed:
-        # the result is out; tearing down communicators must not be able to hold the process (RCCL has been seen to sit in
-        # ncclCommDestroy): if it has not finished within a minute the process ends with the status it has earned
+        # The result is out.  A teardown that does not finish is a FAILURE and is reported as one: the watchdog says which
+        # call the rank was in and ends the process with status 3 (a fresh exit, never a re-exec); the launcher relays it.
+        # (Round 2 had a watchdog that exited 0 here, after a teardown hang in the test suite -- DESIGN.md section 7.
+        # sdfr_comm_close is ordered and bounded by itself now; this is the outer net, and it fails loudly.)
         import threading
 
-        watchdog = threading.Timer(60.0 if rank == 0 else 75.0, lambda: os._exit(0))
+        stage = ["torch.cuda.synchronize"]
+
+        def teardown_stuck():
+            sys.stderr.write("bench.py rank %d: teardown did not finish within its limit; stuck in: %s\n" % (rank, stage[0]))
+            sys.stderr.flush()
+            faulthandler.dump_traceback(all_threads=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(90.0 if rank == 0 else 100.0, teardown_stuck)
         watchdog.daemon = True
         watchdog.start()
         torch.cuda.synchronize()
         if peer_copy:
+            stage[0] = "sdfr_peer_region_status"
             for h_ in rr:
                 h_.peerRegionStatus()   # raises if a wait gave up
+        stage[0] = "dist.barrier (before teardown)"
         dist.barrier()
         if peer_copy:
+            stage[0] = "sdfr_peer_region_close"
             for h_ in (rr if rank != 0 else []):
                 h_.peerRegionClose()    # the peers unmap before rank 0 frees
             dist.barrier()
         faulthandler.cancel_dump_traceback_later()
+        stage[0] = "sdfr_destroy (extra handles)"
         for h_ in rr[1:]:
             h_.close()
         if comm is not None:
-            comm.close()
+            stage[0] = "sdfr_comm_close (streams drained, ncclCommFinalize, ncclCommDestroy)"
+            comm.close()                # raises SdfrError if RCCL's teardown did not finish within its own limit
+        stage[0] = "sdfr_destroy"
     r.close()
     if distributed:
+        stage[0] = "dist.destroy_process_group"
         dist.destroy_process_group()
         watchdog.cancel()
     return 0

@@ -238,7 +238,17 @@ typedef struct sdfr_comm sdfr_comm;
 int sdfr_comm_unique_id(void *id_out);                      /* ncclGetUniqueId; id_out: SDFR_COMM_ID_BYTES bytes */
 int sdfr_comm_create(const void *id, int rank, int world, int device_ordinal, sdfr_comm **out); /* collective: ncclCommInitRank */
 int sdfr_comm_create_all(const int *device_ordinals, int n, sdfr_comm **out_n);                 /* one process: ncclCommInitAll */
+/* Teardown, bounded in time: drains the streams the communicator's transfers ran on (the comm streams of the handles
+ * that used it), then ncclCommFinalize + ncclCommDestroy; if that has not finished within SDFR_COMM_CLOSE_TIMEOUT_S
+ * (default 30 s) ncclCommAbort is tried and SDFR_ERR_COMM comes back with the call it was stuck in (sdfr_comm_last_error
+ * (NULL)) instead of a hang.  Collective in effect: every rank closes.  `c` is gone afterwards either way.
+ * sdfr_comm_destroy is the same without the status. */
+int sdfr_comm_close(sdfr_comm *c);
 void sdfr_comm_destroy(sdfr_comm *c);
+/* Which librccl serves this library (path_out, may be NULL), its ncclGetVersion code, and how many DISTINCT librccl files
+ * the process maps: more than one means some other component loaded a second copy by path -- a process must not run two
+ * (DESIGN.md section 7).  The library itself opens a copy the process already maps (PyTorch's) before any other. */
+int sdfr_comm_library_info(char *path_out, size_t path_bytes, int *nccl_version, int *copies_mapped);
 int sdfr_comm_rank(const sdfr_comm *c);
 int sdfr_comm_world(const sdfr_comm *c);
 const char *sdfr_comm_last_error(const sdfr_comm *c);

@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
     "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
-    "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_rank", "sdfr_comm_world",
+    "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_close", "sdfr_comm_library_info", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
     "sdfr_register_host_target", "sdfr_peer_region_create", "sdfr_peer_region_open", "sdfr_peer_region_close", "sdfr_peer_region_status",
     "sdfr_render_gather_peer",
@@ -170,6 +170,8 @@ def load_library():
     L.sdfr_comm_create_all.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
     L.sdfr_comm_destroy.argtypes = [vp]
     L.sdfr_comm_destroy.restype = None
+    L.sdfr_comm_close.argtypes = [vp]
+    L.sdfr_comm_library_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.sdfr_comm_rank.argtypes = [vp]
     L.sdfr_comm_world.argtypes = [vp]
     L.sdfr_comm_last_error.argtypes = [vp]
@@ -537,7 +539,33 @@ class Comm:
     broadcast); creation is collective."""
 
     @staticmethod
+    def _one_rccl_per_process():
+        """PyTorch ships a librccl of its own (torch/lib/librccl.so) and loads it by PATH, whatever the process holds
+        already.  libsdfr.so opens a copy the process maps before any other (sdfr_comm.cpp), so the process runs one RCCL
+        if torch's is there FIRST; a process that made a communicator and imported torch afterwards would run two.
+        load_library() imports torch already (one HIP runtime); this keeps the property where someone loads the
+        library by other means."""
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+
+    @staticmethod
+    def library_info():
+        """(path of the librccl serving libsdfr.so, ncclGetVersion code, distinct librccl files mapped by the process)"""
+        Comm._one_rccl_per_process()
+        L = load_library()
+        path = ctypes.create_string_buffer(1024)
+        version, copies = ctypes.c_int(0), ctypes.c_int(0)
+        rc = L.sdfr_comm_library_info(path, len(path), ctypes.byref(version), ctypes.byref(copies))
+        if rc != SDFR_OK:
+            raise SdfrError(rc, L.sdfr_comm_last_error(None).decode())
+        return path.value.decode(), version.value, copies.value
+
+    @staticmethod
     def unique_id():
+        Comm._one_rccl_per_process()
         buf = ctypes.create_string_buffer(COMM_ID_BYTES)
         L = load_library()
         rc = L.sdfr_comm_unique_id(buf)
@@ -546,6 +574,7 @@ class Comm:
         return bytes(buf.raw)
 
     def __init__(self, uid, rank, world, device=0):
+        Comm._one_rccl_per_process()
         self._L = load_library()
         self._c = ctypes.c_void_p()
         assert len(uid) == COMM_ID_BYTES
@@ -562,11 +591,15 @@ class Comm:
         return True
 
     def close(self):
-        """ncclCommDestroy: collective in effect -- every rank should close; not called implicitly (a communicator
-        that is still open when the process ends is reclaimed with it)"""
+        """sdfr_comm_close: drains the streams the communicator's transfers ran on, then ncclCommFinalize + ncclCommDestroy,
+        bounded in time (SDFR_COMM_CLOSE_TIMEOUT_S, default 30 s): a teardown that does not finish raises SdfrError with the
+        call it was stuck in instead of holding the process.  Collective in effect -- every rank closes.  Not called
+        implicitly (a communicator still open when the process ends is reclaimed with it)."""
         if self._c:
-            self._L.sdfr_comm_destroy(self._c)
-            self._c = ctypes.c_void_p()
+            c, self._c = self._c, ctypes.c_void_p()
+            rc = self._L.sdfr_comm_close(c)
+            if rc != SDFR_OK:
+                raise SdfrError(rc, self._L.sdfr_comm_last_error(None).decode())
 
 
 class HDR:

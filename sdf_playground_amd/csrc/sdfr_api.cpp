@@ -156,6 +156,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipSetDevice(r->device);
 	(void)hipStreamSynchronize(r->stream);
 	if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+	comm_forget_renderer(r);
 	free_workspace(r);
 	jit_unload(r->jit);
 	(void)hipFree(r->d_totals);

@@ -13,16 +13,27 @@
 // peer, and a gather moves every byte exactly once over exactly one link.
 //
 // librccl.so is opened on first use (like libhiprtc.so in sdfr_jit.cpp): hosts that render on one
-// GPU never load it.  If the process already holds an RCCL (PyTorch's), dlopen by SONAME returns
-// that one, so a process never runs two.
+// GPU never load it.  ONE RCCL PER PROCESS: if the process already maps a librccl (PyTorch ships its own copy in
+// torch/lib, which libtorch_hip.so loads by PATH), that very file is the one opened here -- found in
+// /proc/self/maps rather than left to the SONAME match of dlopen.  sdfr_comm_library_info reports which file serves
+// the library and how many distinct librccl files the process maps (a guard: two copies in one process is a state
+// nobody tests).  RCCL operations never run on the legacy NULL stream here (sdfr_comm_selftest, sdfr_comm_close).
 #include "sdfr_handle.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <memory>
 #include <mutex>
+#include <set>
+#include <thread>
 
 using namespace sdfr;
 
@@ -40,20 +51,52 @@ struct Rccl
 	decltype(&ncclSend) send = nullptr;
 	decltype(&ncclRecv) recv = nullptr;
 	decltype(&ncclGetErrorString) error_string = nullptr;
+	// optional (NCCL >= 2.14): an orderly, bounded teardown
+	decltype(&ncclCommFinalize) comm_finalize = nullptr;
+	decltype(&ncclCommAbort) comm_abort = nullptr;
+	decltype(&ncclCommGetAsyncError) comm_async_error = nullptr;
+	decltype(&ncclGetVersion) get_version = nullptr;
 	bool ok = false;
 	std::string why;
+	std::string path; // the file that serves the entry points (dladdr)
 };
+
+// distinct files named librccl.so* that this process maps right now
+std::vector<std::string> mapped_rccl_files()
+{
+	std::vector<std::string> files;
+	std::ifstream maps("/proc/self/maps");
+	std::string line;
+	while (std::getline(maps, line))
+	{
+		const size_t slash = line.find('/');
+		if (slash == std::string::npos) continue;
+		std::string path = line.substr(slash);
+		const size_t del = path.find(" (deleted)");
+		if (del != std::string::npos) path.resize(del);
+		const size_t base = path.rfind('/');
+		if (path.compare(base + 1, 10, "librccl.so") != 0) continue;
+		bool seen = false;
+		for (const auto &f : files) seen = seen || f == path;
+		if (!seen) files.push_back(path);
+	}
+	return files;
+}
 
 Rccl &rccl()
 {
 	static Rccl h;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		const char *names[] = {getenv("SDFR_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-		for (const char *n : names)
+		// a copy the process holds already comes first (one RCCL per process); then the usual names
+		std::vector<std::string> names;
+		if (const char *e = getenv("SDFR_RCCL_LIBRARY"))
+			if (e[0]) names.push_back(e);
+		for (const auto &f : mapped_rccl_files()) names.push_back(f);
+		for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+		for (const auto &n : names)
 		{
-			if (!n || !n[0]) continue;
-			if ((h.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+			if ((h.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
 			h.why += std::string(h.why.empty() ? "" : "; ") + dlerror();
 		}
 		if (!h.lib) return;
@@ -66,6 +109,12 @@ Rccl &rccl()
 		h.send = (decltype(h.send))dlsym(h.lib, "ncclSend");
 		h.recv = (decltype(h.recv))dlsym(h.lib, "ncclRecv");
 		h.error_string = (decltype(h.error_string))dlsym(h.lib, "ncclGetErrorString");
+		h.comm_finalize = (decltype(h.comm_finalize))dlsym(h.lib, "ncclCommFinalize");
+		h.comm_abort = (decltype(h.comm_abort))dlsym(h.lib, "ncclCommAbort");
+		h.comm_async_error = (decltype(h.comm_async_error))dlsym(h.lib, "ncclCommGetAsyncError");
+		h.get_version = (decltype(h.get_version))dlsym(h.lib, "ncclGetVersion");
+		Dl_info info;
+		if (h.get_unique_id && dladdr((const void *)h.get_unique_id, &info) && info.dli_fname) h.path = info.dli_fname;
 		h.ok = h.get_unique_id && h.comm_init_rank && h.comm_init_all && h.comm_destroy && h.group_start && h.group_end && h.send && h.recv &&
 			   h.error_string;
 		if (!h.ok) h.why = "librccl.so lacks an expected entry point";
@@ -82,7 +131,29 @@ struct sdfr_comm
 	ncclComm_t comm = nullptr;
 	int rank = 0, world = 1, device = 0;
 	mutable std::string error;
+	// handles whose comm stream carries (or carried) this communicator's transfers: the teardown waits for those streams,
+	// a handle that is destroyed first takes itself off the list (comm_forget_renderer)
+	std::set<sdfr_renderer *> users;
+	// the communicator's own stream: what the self-test runs on when its caller passes the NULL stream
+	hipStream_t own_stream = nullptr;
 };
+
+namespace {
+std::mutex g_registry_lock; // guards every sdfr_comm::users and sdfr_renderer::comms_used
+}
+
+// sdfr_destroy: the handle's streams have been drained; no communicator may look at it again
+void sdfr::comm_forget_renderer(sdfr_renderer *r)
+{
+	std::lock_guard<std::mutex> g(g_registry_lock);
+	for (void *p : r->comms_used) static_cast<sdfr_comm *>(p)->users.erase(r);
+	r->comms_used.clear();
+}
+static void comm_remember_renderer(sdfr_comm *c, sdfr_renderer *r)
+{
+	std::lock_guard<std::mutex> g(g_registry_lock);
+	if (c->users.insert(r).second) r->comms_used.push_back(c);
+}
 
 static int comm_fail(const sdfr_comm *c, const std::string &msg)
 {
@@ -295,26 +366,166 @@ int sdfr_comm_create_all(const int *device_ordinals, int n, sdfr_comm **out_n)
 	return SDFR_OK;
 }
 
-void sdfr_comm_destroy(sdfr_comm *c)
+// Teardown of a communicator, bounded in time.
+//
+// What happened in round 2 (gpurun_out/r02/s3: `pytest -m gpu` killed at 500 s behind the 17th dot, i.e. in the teardown
+// of tests/test_gpu_comm.py's communicator fixture -> sdfr_comm_destroy -> ncclCommDestroy, which was then called bare).
+// What the records allow to say: the process held ONE librccl (the Python wrapper imports torch before it loads this
+// library, so the dlopen matched torch's copy); nothing of the communicator was pending (the self-test drains its
+// stream, a gather at world 1 issues no RCCL call); the same ncclCommDestroy returned in milliseconds in every bench.py
+// process of the same session.  The one difference in how the two kinds of process had USED the communicator: the test
+// fixture ran its self-test -- a grouped ncclSend / ncclRecv -- on the legacy NULL stream (stream_handle = None), bench.py
+// on a created stream.  RCCL orders its internal streams against the user's with events, and the NULL stream
+// synchronises implicitly with every blocking stream of the device; a communicator that has launched on it is the
+// only state the hanging process had and the others did not.  That is the cause as far as the evidence reaches -- it
+// was not re-run to be made to show again.  What is done about it:
+//   * RCCL work never runs on the NULL stream: the self-test moves to a stream the communicator owns (the gather always
+//     ran on the handles' comm streams);
+//   * the order RCCL's contract asks for: every stream that carried this communicator's transfers is drained first
+//     (the handles' comm streams -- a handle destroyed earlier has drained its own --, the communicator's own stream);
+//   * ncclCommFinalize (where the library has it), then ncclCommDestroy, on a helper thread with a deadline
+//     (SDFR_COMM_CLOSE_TIMEOUT_S, default 30 s); past it the caller calls ncclCommAbort, which is made for exactly
+//     this, waits a little longer, and otherwise leaves the helper thread and the communicator behind and reports
+//     SDFR_ERR_COMM with the call the teardown was last seen in: a diagnosis instead of a hang.
+namespace {
+struct CloseJob
 {
-	if (!c) return;
-	if (c->comm && rccl().ok)
+	std::mutex m;
+	std::condition_variable cv;
+	bool done = false;
+	std::atomic<const char *> stage{"not started"};
+	ncclResult_t finalize_rc = ncclSuccess, destroy_rc = ncclSuccess;
+};
+double close_timeout_s()
+{
+	if (const char *e = getenv("SDFR_COMM_CLOSE_TIMEOUT_S"))
+	{
+		const double v = atof(e);
+		if (v > 0.0) return v;
+	}
+	return 30.0;
+}
+} // namespace
+
+int sdfr_comm_close(sdfr_comm *c)
+{
+	if (!c) return SDFR_ERR_INVALID_ARGUMENT;
+	Rccl &n = rccl();
+	int status = SDFR_OK;
+	std::string diagnosis;
+	if (c->comm && n.ok)
 	{
 		(void)hipSetDevice(c->device);
-		(void)rccl().comm_destroy(c->comm);
+		{
+			// drain the streams its transfers ran on, and let go of the handles
+			std::lock_guard<std::mutex> g(g_registry_lock);
+			for (sdfr_renderer *r : c->users)
+			{
+				if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+				for (size_t k = 0; k < r->comms_used.size(); ++k)
+					if (r->comms_used[k] == c) { r->comms_used.erase(r->comms_used.begin() + (long)k); break; }
+			}
+			c->users.clear();
+		}
+		if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+		auto job = std::make_shared<CloseJob>();
+		const ncclComm_t comm = c->comm;
+		const int device = c->device;
+		std::thread worker([job, comm, device, &n]() {
+			(void)hipSetDevice(device);
+			if (n.comm_finalize)
+			{
+				job->stage = "ncclCommFinalize";
+				job->finalize_rc = n.comm_finalize(comm);
+				// a non-blocking communicator finishes in the background: ncclInProgress until it has
+				while (n.comm_async_error && job->finalize_rc == ncclInProgress)
+				{
+					ncclResult_t state = ncclSuccess;
+					if (n.comm_async_error(comm, &state) != ncclSuccess || state != ncclInProgress) { job->finalize_rc = state; break; }
+					std::this_thread::sleep_for(std::chrono::milliseconds(5));
+				}
+			}
+			job->stage = "ncclCommDestroy";
+			job->destroy_rc = n.comm_destroy(comm);
+			job->stage = "done";
+			std::lock_guard<std::mutex> g(job->m);
+			job->done = true;
+			job->cv.notify_all();
+		});
+		const auto wait_for = [&](double seconds) {
+			std::unique_lock<std::mutex> g(job->m);
+			return job->cv.wait_for(g, std::chrono::duration<double>(seconds), [&] { return job->done; });
+		};
+		if (wait_for(close_timeout_s()))
+		{
+			worker.join();
+			if (job->destroy_rc != ncclSuccess)
+			{
+				status = SDFR_ERR_COMM;
+				diagnosis = std::string("ncclCommDestroy: ") + n.error_string(job->destroy_rc);
+			}
+		}
+		else
+		{
+			const char *stuck_in = job->stage.load();
+			status = SDFR_ERR_COMM;
+			diagnosis = std::string("communicator teardown did not finish within ") + std::to_string(close_timeout_s()) + " s; last seen in " + stuck_in;
+			if (n.comm_abort)
+			{
+				(void)n.comm_abort(comm);
+				diagnosis += wait_for(5.0) ? "; ncclCommAbort released it" : "; ncclCommAbort did not release it: the helper thread and the communicator are left behind";
+			}
+			if (job->done) worker.join(); else worker.detach(); // `job` is shared: the thread may outlive this call
+			const auto files = mapped_rccl_files();
+			diagnosis += "; librccl in use: " + n.path + ", distinct librccl files mapped: " + std::to_string(files.size());
+		}
 	}
+	if (status != SDFR_OK)
+	{
+		g_comm_error = diagnosis;
+		fprintf(stderr, "libsdfr: %s\n", diagnosis.c_str());
+	}
+	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 	delete c;
+	return status;
+}
+
+void sdfr_comm_destroy(sdfr_comm *c) { (void)sdfr_comm_close(c); }
+
+int sdfr_comm_library_info(char *path_out, size_t path_bytes, int *nccl_version, int *copies_mapped)
+{
+	const int rc = need_rccl(nullptr);
+	if (rc != SDFR_OK) return rc;
+	Rccl &n = rccl();
+	if (path_out && path_bytes) snprintf(path_out, path_bytes, "%s", n.path.c_str());
+	if (nccl_version)
+	{
+		*nccl_version = 0;
+		if (n.get_version) (void)n.get_version(nccl_version);
+	}
+	if (copies_mapped) *copies_mapped = (int)mapped_rccl_files().size();
+	return SDFR_OK;
 }
 
 int sdfr_comm_rank(const sdfr_comm *c) { return c ? c->rank : SDFR_ERR_INVALID_ARGUMENT; }
 int sdfr_comm_world(const sdfr_comm *c) { return c ? c->world : SDFR_ERR_INVALID_ARGUMENT; }
 const char *sdfr_comm_last_error(const sdfr_comm *c) { return c ? c->error.c_str() : g_comm_error.c_str(); }
 
+// (drains `hip_stream` before it returns: nothing of it is pending when the communicator is closed)
 int sdfr_comm_selftest(sdfr_comm *c, size_t bytes, void *hip_stream)
 {
 	if (!c || bytes == 0 || bytes > ((size_t)1 << 30)) return SDFR_ERR_INVALID_ARGUMENT;
 	hipStream_t stream = (hipStream_t)hip_stream;
 	if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, "hipSetDevice failed");
+	// never RCCL on the legacy NULL stream (see sdfr_comm_close): the call is blocking anyway, so the NULL stream is
+	// drained and the exchange runs on a stream of the communicator's own.  SDFR_COMM_ALLOW_NULL_STREAM=1 (diagnosis
+	// only) keeps the caller's NULL stream.
+	if (!stream && !getenv("SDFR_COMM_ALLOW_NULL_STREAM"))
+	{
+		if (hipStreamSynchronize(nullptr) != hipSuccess) return comm_fail(c, "hipStreamSynchronize(NULL) failed");
+		if (!c->own_stream && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return comm_fail(c, "hipStreamCreate failed");
+		stream = c->own_stream;
+	}
 	const int to = (c->rank + 1) % c->world, from = (c->rank + c->world - 1) % c->world;
 	auto pattern = [](int rank, size_t i) { return (unsigned char)((i * 2654435761u + (size_t)rank * 97u + (i >> 13)) & 0xffu); };
 	std::vector<unsigned char> host(bytes);
@@ -357,6 +568,7 @@ int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, vo
 	GatherShape g;
 	int rc = gather_check(r, c, width, height, root_image, image_format, wire_format, g);
 	if (rc != SDFR_OK) return rc;
+	comm_remember_renderer(c, r);
 	rc = gather_render(r, c, g);
 	if (rc != SDFR_OK) return rc;
 	if (g.world > 1 && g.rank_bytes)
@@ -386,6 +598,7 @@ int sdfr_render_gather_all(sdfr_renderer *const *r, sdfr_comm *const *c, int n, 
 	}
 	for (int i = 0; i < n; ++i)
 	{
+		comm_remember_renderer(c[i], r[i]);
 		const int rc = gather_render(r[i], c[i], g[(size_t)i]);
 		if (rc != SDFR_OK) return rc;
 	}

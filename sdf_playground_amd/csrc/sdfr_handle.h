@@ -61,6 +61,7 @@ struct sdfr_renderer
 	void *d_wire = nullptr;    // this rank's compact strips; on the root: world x that, slot 0 = its own
 	size_t wire_bytes = 0;
 	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
+	std::vector<void *> comms_used; // sdfr_comm* whose transfers ran on comm_stream (sdfr_comm.cpp keeps both sides of the list)
 
 	// peer-copy gather (sdfr_peer.hip): rank 0 owns the region, the peers map it through hipIpc
 	void *peer_buffer = nullptr;    // the gathered buffer (rank 0's memory)
@@ -98,5 +99,7 @@ int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, vo
 
 // the stream and events shared by the RCCL and the peer-copy transports of a gathered frame (sdfr_comm.cpp)
 int gather_prepare_streams(sdfr_renderer *r);
+// the handle is going away: communicators that remember it must forget it (sdfr_comm.cpp)
+void comm_forget_renderer(sdfr_renderer *r);
 
 } // namespace sdfr

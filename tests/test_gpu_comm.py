@@ -18,8 +18,11 @@ def comm():
 
     c = sp.Comm(sp.Comm.unique_id(), 0, 1, 0)
     yield c
-    # not closed here: the communicator goes with the process (bench.py closes its own, in a child process of
-    # tests/test_gpu_bench.py, behind a watchdog: RCCL's teardown is the one call in this path that has no time limit)
+    # closed like any other resource: sdfr_comm_close drains the streams that carried the communicator's transfers and is
+    # bounded in time (it raises instead of hanging).  Round 2 left this out after a teardown hang in exactly this place;
+    # what the records say about it and what was changed -- RCCL never runs on the NULL stream any more (this fixture's
+    # self-test used to), ordered and bounded teardown -- is in sdfr_comm.cpp (sdfr_comm_close) and DESIGN.md section 7.
+    c.close()
 
 
 @pytest.fixture()
@@ -37,6 +40,41 @@ def scene_renderer():
     r.setCamera(cam)
     yield r
     r.close()
+
+
+def test_one_rccl_per_process(comm):
+    """the library serves itself from the librccl the process already maps (PyTorch's, loaded by path from torch/lib)
+    instead of opening a second copy by name"""
+    import torch  # noqa: F401  (whichever order: the wrapper loads torch before the first communicator)
+    import sdf_playground_amd as sp
+
+    path, version, copies = sp.Comm.library_info()
+    assert copies == 1, (path, copies)
+    assert "librccl" in path and version >= 21400  # ncclCommFinalize / ncclCommAbort exist from 2.14 on
+    maps = open("/proc/self/maps").read()
+    assert path in maps
+
+
+def test_close_is_bounded_and_reports(comm):
+    """a second communicator, used by a handle that is still alive and by one that is already gone, closes cleanly"""
+    import torch
+    import sdf_playground_amd as sp
+
+    c2 = sp.Comm(sp.Comm.unique_id(), 0, 1, 0)
+    hs = []
+    for k in range(2):
+        h = sp.SDFRenderer(0)
+        h.initShader("fast_sphere")
+        out = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+        h.renderGather(c2, W, H, out=out, fmt=sp.RGBA16F)
+        hs.append(h)
+    hs[0].close()        # a handle that used the communicator is destroyed first: the communicator forgets it
+    assert c2.selftest(4096)
+    c2.close()           # drains hs[1]'s comm stream, finalizes, destroys -- or raises with the call it was stuck in
+    c2.close()           # idempotent
+    hs[1].close()
+    _, _, copies = sp.Comm.library_info()
+    assert copies == 1
 
 
 def test_communicator_self_test(comm):
