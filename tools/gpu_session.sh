@@ -13,6 +13,8 @@ for spec in "$@"; do
   rc=$?
   echo "=== $name rc=$rc $(( $(date +%s) - start )) s" | tee -a $OUT/session.log
   tail -n 6 $OUT/$name.log
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step hung or was killed: stopping" | tee -a $OUT/session.log; exit 1; fi
+  # a step that timed out, was killed or died of a signal (134 = SIGABRT: the HIP runtime aborts on a GPU memory fault; 139 = SIGSEGV)
+  # ends the session: no further GPU step after a hang or a fault
+  if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "step hung, was killed or aborted (rc $rc): stopping" | tee -a $OUT/session.log; exit 1; fi
 done
 exit 0
