@@ -44,8 +44,8 @@ SPLIT_PERIOD = 16     # strips per period of the private/shared split (N > 1)
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec); 2 flop per lane per FMA at the packed rate
 PEAK_VALU_LANE_OPS = 78.6e12      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: what the VALU can issue, one op per lane per cycle
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md (spec)
-PROFILE_ROUND = "r02"
-CENSUS_FILE = os.path.join(ROOT, "profiles", "census_%s.json" % PROFILE_ROUND)
+PROFILE_ROUND = "r02"   # the round whose committed counter profiles (profiles/pmc_<round>_cfg<c>.json) feed `roofline.executed`
+CENSUS_FILE = os.path.join(ROOT, "profiles", "census_r03.json")
 
 
 def pcg_hash(x):
@@ -86,7 +86,18 @@ def _cam5_gems(k):
     return "lookat", (2.5 * math.cos(t), 2.0, 2.5 * math.sin(t)), (0.0, 1.0, 0.0), k / 60.0
 
 
+def _cam1(k):
+    return "lookat", (0.0, 2.0, -3.0), (0.0, 1.0, 0.0), 0.0   # the reference's start-up camera (Application.cpp:214-224)
+
+
 CONFIGS = {
+    # BASELINE.json configs[0]: "Single sphere SDF, 256x256, 64 max steps, 1 light, no secondary rays -- CPU scalar raymarch of scene()
+    # (plumbing, no GPU)".  SURVEY.md 8(d) cfg 1: fast_sphere, iter_count 64, max_cost_default 2 (no child ray passes depth + 2 < 2).
+    # `python bench.py --config 1` is the CPU line (the oracle, in full); it needs no GPU and renders on one only if there is one.
+    "1": dict(key="fast_sphere_256_iter64", scene="fast_sphere", width=256, height=256, limits=dict(iter_count=64, max_cost_default=2),
+              camera=_cam1, metric="Mrays/s (primary rays only), fast_sphere scene, 256x256, CPU scalar raymarch",
+              workload="fast_sphere %dx%d, iter_count 64, max_cost_default 2 (no secondary rays; both labelled extensions of the reference's 100 / 7), "
+                       "the reference's start-up camera, stime 0"),
     "2": dict(key="cube_sea_1080p_iter128", scene="cube_sea", width=1920, height=1080, limits=dict(iter_count=128, max_cost_default=6),
               camera=_cam2, metric="Mrays/s (primary+secondary), cube_sea scene, 1920x1080",
               workload="cube_sea %dx%d, iter_count 128, max_cost_default 6 (= exactly one reflection bounce, the configuration as worded; labelled "
@@ -256,6 +267,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-steps", action="store_true",
                     help="march every step of every ray (sdfr_set_step_shortcuts off): the step counters then equal the reference's; the pixels are the same either way")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="N = 1: after the K timed steps keep looping the sweep for at least this long and report that steady-state figure beside "
+                         "the K-step one (`steady`): 32 steps are 40 ms, shorter than a clock ramp")
+    ap.add_argument("--no-extra-passes", action="store_true",
+                    help="N = 1: skip the informational passes after the timed region (every step marched; the reference's own iter_count 100)")
     ap.add_argument("--no-second-pass", action="store_true",
                     help="skip the informational two-frames-in-flight pass (N = 1): under a profiler its overlapping kernels would pollute the per-kernel statistics")
     ap.add_argument("--width", type=int, default=0)
@@ -358,7 +374,71 @@ def main(argv=None):
         return 2
     if a.dry_launch:
         return dry_launch(a)
+    if a.config == "1":
+        return run_config1(a)
     return run(a, world)
+
+
+def run_config1(a):
+    """BASELINE.json configs[0]: the CPU scalar raymarch of fast_sphere at 256x256, 64 steps, no secondary rays -- the oracle,
+    in full (every pixel, every step), threaded over the host cores the box grants; K steps = K renders of the frame.  No GPU
+    is needed; if one is there the HIP path renders the same frame as well (reported beside, and compared bit for bit)."""
+    import numpy as np
+    from oracle import pyoracle as po
+
+    cfg = CONFIGS["1"]
+    W, H = a.width or cfg["width"], a.height or cfg["height"]
+    f = oracle_frame(po, 0, W, H, "1")
+    cores = host_cores()
+    for _ in range(max(1, a.warmup)):
+        ref, rst, tot = po.render(cfg["scene"], f, stats=True, nthreads=cores)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        po.render(cfg["scene"], f, nthreads=cores)
+    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    po.render(cfg["scene"], f, nthreads=1)
+    single = time.perf_counter() - t1
+    rays = int(tot[1])
+    out = {
+        "metric": cfg["metric"], "value": rays * a.steps / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": 0, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["workload"] % (W, H), "baseline_config": "1", "parallelism": "cpu%d" % cores,
+                   "rays_per_pixel": rays / float(W * H), "march_evals_per_ray": float(tot[2]) / max(1, rays)},
+        "cpu_baseline": {"value": rays * a.steps / elapsed / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                         "sample": "oracle (scalar C++ restatement, g++ -O2 -ffp-contract=off), the whole %dx%d frame, %d renders, %.2f s; one thread: %.3f Mrays/s"
+                                   % (W, H, a.steps, elapsed, rays / single / 1e6)},
+    }
+    try:
+        import torch
+
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        import sdf_playground_amd as sp
+
+        r = sp.SDFRenderer(0)
+        r.initShader(cfg["scene"])
+        r.setLimits(**cfg["limits"])
+        cam, stime = make_camera(0, W, H, "1")
+        r.setParameters(stime)
+        img = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            r.render(cam, W, H, out=img)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            r.render(None, W, H, out=img)
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t2) / a.steps * 1e3
+        st = r.getStats()
+        out["gpu"] = {"ms_per_step": gms, "value": float(st.rays) / (gms * 1e-3) / 1e6, "unit": "Mrays/s", "kernel_ms": st.ms_gpu,
+                      "bit_identical_to_cpu": bool(np.array_equal(img.cpu().numpy().view(np.uint32), ref.view(np.uint32))) and int(st.rays) == rays,
+                      "note": "the HIP path on the same frame, informational: a 65 536-pixel frame is 1 024 waves, a seventh of what the chip holds"}
+        r.close()
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def run(a, world):
@@ -775,6 +855,60 @@ def run(a, world):
                 r2.close()
             except Exception as e:
                 out["two_frames_in_flight"] = {"error": repr(e)}
+        if not distributed and not a.no_extra_passes:
+            # Informational passes over the same 16 sweep frames, after the timed region, one frame in flight:
+            #   exact_steps        every step of every ray marched (sdfr_set_step_shortcuts off): the reference's own step count
+            #   reference_limits   the reference's compile-time limits untouched (iter_count 100, max_cost 7, ...): "pure reference"
+            def extra_pass(limits, shortcuts):
+                h = make_renderer(stream)
+                h.setLimits(**limits)
+                h.setStepShortcuts(shortcuts)
+                for k in range(3):
+                    h.setParameters(cameras[k][1])
+                    h.render(cameras[k][0], W, H, out=image)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for k in range(SWEEP):
+                    h.setParameters(cameras[k][1])
+                    h.render(cameras[k][0], W, H, out=image)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - tp) / SWEEP * 1e3
+                rays = evals = 0
+                for k in range(SWEEP):
+                    h.setParameters(cameras[k][1])
+                    h.render(cameras[k][0], W, H, out=image)
+                    st = h.getStats()
+                    rays += int(st.rays)
+                    evals += int(st.march_evals)
+                h.close()
+                return {"ms_per_step": ms, "value": rays / SWEEP / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "rays_per_pixel": rays / SWEEP / float(W * H),
+                        "march_evals_per_ray": evals / max(1, rays)}
+
+            try:
+                if not a.exact_steps:
+                    out["exact_steps"] = dict(extra_pass(cfg["limits"], False), note="every step marched (step shortcuts off): the reference's step count; same pixels, rays and hits")
+                ref_limits = dict(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0,
+                                  extension_marble_reflection=0.0)
+                out["reference_limits"] = dict(extra_pass(ref_limits, not a.exact_steps),
+                                               note="the reference's own limits (iter_count 100, max_cost 7, one light table): pure reference semantics, SURVEY.md 8(d)")
+            except Exception as e:
+                out["extra_passes_error"] = repr(e)
+        if not distributed and a.min_seconds > 0:
+            # a steady-state figure: the same steps, looped for at least --min-seconds (the K-step region is tens of milliseconds)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            n_steady = 0
+            while True:
+                for s in range(SWEEP):
+                    step(n_steady + s)
+                n_steady += SWEEP
+                torch.cuda.synchronize()
+                if time.perf_counter() - ts >= a.min_seconds:
+                    break
+            secs = time.perf_counter() - ts
+            rays_steady = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(n_steady))
+            out["steady"] = {"seconds": secs, "steps": n_steady, "ms_per_step": secs / n_steady * 1e3, "value": rays_steady / secs / 1e6, "unit": "Mrays/s",
+                             "note": "the sweep looped for >= --min-seconds, a synchronisation every 16 steps"}
         if not distributed and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.config, W, H)

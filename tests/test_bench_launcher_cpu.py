@@ -59,7 +59,7 @@ def c_ref(bench):
 def test_configurations_are_the_ones_survey_8d_defines():
     import bench
 
-    assert sorted(bench.CONFIGS) == ["2", "3", "3r", "4", "5", "5g"]
+    assert sorted(bench.CONFIGS) == ["1", "2", "3", "3r", "4", "5", "5g"]
     assert c_ref(bench)
     c = bench.CONFIGS
     assert (c["2"]["scene"], c["2"]["width"], c["2"]["height"], c["2"]["limits"]["iter_count"]) == ("cube_sea", 1920, 1080, 128)
@@ -70,7 +70,10 @@ def test_configurations_are_the_ones_survey_8d_defines():
     # the sweeps are deterministic and differ frame to frame
     for k, cfg in c.items():
         cams = [cfg["camera"](i) for i in range(bench.SWEEP)]
-        assert cams == [cfg["camera"](i) for i in range(bench.SWEEP)] and len({cm[1] for cm in cams}) == bench.SWEEP
+        assert cams == [cfg["camera"](i) for i in range(bench.SWEEP)] and len({cm[1] for cm in cams}) == (1 if k == "1" else bench.SWEEP)
+    # configuration 1: the reference's start-up camera, no secondary rays (Application.cpp:214-224; SURVEY.md 8d cfg 1)
+    assert (c["1"]["scene"], c["1"]["width"], c["1"]["height"], c["1"]["limits"]) == ("fast_sphere", 256, 256, {"iter_count": 64, "max_cost_default": 2})
+    assert c["1"]["camera"](7) == ("lookat", (0.0, 2.0, -3.0), (0.0, 1.0, 0.0), 0.0)
     # the full-size GPU parity test and the bench agree on the cameras (frame 5)
     import tests.test_gpu_fullsize as tf
 
@@ -78,3 +81,22 @@ def test_configurations_are_the_ones_survey_8d_defines():
     for k, scene in (("2", "cube_sea"), ("3", "labyrinth"), ("4", "fractal"), ("5", "lense"), ("5g", "gems")):
         kind, eye, tgt, stime = c[k]["camera"](5)
         assert by_scene[scene][4] == (kind, eye, tgt) and by_scene[scene][5] == stime and by_scene[scene][3] == c[k]["limits"]
+
+
+def test_config_1_is_the_cpu_line_and_needs_no_gpu():
+    """BASELINE.json configs[0] (SURVEY.md 8d cfg 1): fast_sphere 256x256, 64 steps, no secondary rays, the CPU scalar
+    raymarch in full -- `bench.py --config 1` prints the contract's one JSON line from the oracle alone"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "1", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 0 and d["unit"] == "Mrays/s" and d["value"] > 0 and d["steps"] == 3 and d["config"]["baseline_config"] == "1"
+    assert d["config"]["rays_per_pixel"] == 1.0  # max_cost_default 2: no child ray is ever spawned
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "whole 256x256 frame" in d["cpu_baseline"]["sample"]

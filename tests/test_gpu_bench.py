@@ -22,6 +22,19 @@ def _run(extra):
     return json.loads(lines[0])
 
 
+def test_bench_extra_passes_and_steady_state():
+    """N = 1 extras: every step marched, the reference's own limits, and a sweep looped for --min-seconds"""
+    d = _run(["--min-seconds", "0.3", "--no-second-pass"])
+    ex, rl, st = d["exact_steps"], d["reference_limits"], d["steady"]
+    assert ex["value"] > 0 and rl["value"] > 0 and st["value"] > 0 and st["seconds"] >= 0.3 and st["steps"] % 16 == 0
+    # same frames: the rays do not depend on the shortcuts; marching every step costs evaluations
+    assert abs(ex["rays_per_pixel"] - d["config"]["rays_per_pixel"]) < 1e-9
+    assert rl["march_evals_per_ray"] <= ex["march_evals_per_ray"]  # iter_count 100 instead of 256, and shortcuts on
+    assert "exact_steps" not in _run(["--no-extra-passes", "--no-second-pass"])
+    c1 = _run(["--config", "1"])
+    assert c1["n_gpus"] == 0 and c1["gpu"]["bit_identical_to_cpu"] is True and c1["gpu"]["value"] > c1["value"]
+
+
 def test_bench_single_rank_line():
     d = _run([])
     assert d["verified"] is True and d["n_gpus"] == 1 and d["steps"] == 7 and d["unit"] == "Mrays/s"

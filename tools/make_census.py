@@ -17,7 +17,7 @@ import bench
 from oracle import pyoracle as po
 
 po.build(census=True, ref=False)
-STEP = {"2": 8}  # 1920x1080: a denser sample for a similar pixel count
+STEP = {"2": 8, "1": 1}  # 1920x1080: a denser sample for a similar pixel count; 256x256: every pixel
 configs = sys.argv[1:] or sorted(bench.CONFIGS)
 try:
     with open(bench.CENSUS_FILE) as fh:
