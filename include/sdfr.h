@@ -72,6 +72,20 @@ int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *sourc
  * SDFR_ERR_COMPILE / SDFR_ERR_INVALID_ARGUMENT with the messages in `log`.  arch: "gfx950" (NULL = that). */
 int sdfr_check_scene_source(const char *source, const char *arch, char *log, size_t log_bytes);
 
+/* The same for a scene IN THE REFERENCE'S OWN DIALECT: the text of an .hlsl scene file as Application::loadScene substitutes
+ * it for "sdf_scene.hlsl" (Application.cpp:229,320; pshader_sdf.hlsl:84) -- the four callbacks map / map_normal / map_light /
+ * map_background with their HLSL signatures (sdf_structs.hlsl), the OBJECT / OBJECT_TRANSPARENT / MATERIAL macros
+ * (pshader_sdf.hlsl:79-81), float2/3/4 with swizzles, the intrinsics, the shader libraries under their own names
+ * (sdSphere ... turbulence), the frame globals (stime, eye, ...), VAR_ tags.  The 22 scene files of the reference load as
+ * they are (their `#include "sdf_*.hlsl"` lines are dropped: the libraries are this library's).  The text is compiled as
+ * the body of a C++ class after a short textual pass (csrc/sdfr_hlsl.h, sdfr_hlsl.cpp); plain IEEE arithmetic, like every
+ * run-time scene.  Not supported: snoise(float2) / snoise(float4), HLSL objects that have no meaning here (textures,
+ * samplers, semantics).  sdfr_translate_scene_hlsl returns the generated C++ (bytes needed incl. the terminator; `out` may
+ * be NULL) -- for inspection and for compiling a scene with a host compiler. */
+int sdfr_load_scene_hlsl(sdfr_renderer *r, const char *name, const char *hlsl_source);
+int sdfr_check_scene_hlsl(const char *hlsl_source, const char *arch, char *log, size_t log_bytes);
+int sdfr_translate_scene_hlsl(const char *hlsl_source, char *out, size_t out_bytes);
+
 /* ---- parameter surface 1: shader variables = SDFRenderer::getVariableMap()
  *      (ShaderVariable.h:6-12; ShaderUtil.cpp:122-267).  Index order = std::map order
  *      (lexicographic by name), which is also the reference's constant-buffer order. --------- */

@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
+    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_load_scene_hlsl", "sdfr_check_scene_hlsl", "sdfr_translate_scene_hlsl", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_close", "sdfr_comm_library_info", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
@@ -122,6 +122,9 @@ def load_library():
     L.sdfr_load_scene.argtypes = [vp, ctypes.c_char_p]
     L.sdfr_load_scene_source.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
     L.sdfr_check_scene_source.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.sdfr_load_scene_hlsl.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.sdfr_check_scene_hlsl.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.sdfr_translate_scene_hlsl.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.sdfr_current_scene.argtypes = [vp]
     L.sdfr_current_scene.restype = ctypes.c_char_p
     L.sdfr_var_count.argtypes = [vp]
@@ -196,6 +199,30 @@ def check_scene_source(source, arch="gfx950"):
     log = ctypes.create_string_buffer(1 << 16)
     rc = load_library().sdfr_check_scene_source(source.encode(), arch.encode(), log, len(log))
     return rc == SDFR_OK, log.value.decode(errors="replace")
+
+
+def check_scene_hlsl(source, arch="gfx950"):
+    """Compile a scene written in the reference's dialect (an .hlsl scene file's text, or its path) without a device;
+    returns (ok, compiler messages).  sdfr_check_scene_hlsl."""
+    if os.path.exists(source):
+        with open(source) as f:
+            source = f.read()
+    log = ctypes.create_string_buffer(1 << 16)
+    rc = load_library().sdfr_check_scene_hlsl(source.encode(), arch.encode(), log, len(log))
+    return rc == SDFR_OK, log.value.decode(errors="replace")
+
+
+def translate_scene_hlsl(source):
+    """The C++ the library generates from a scene in the reference's dialect (sdfr_translate_scene_hlsl): `struct UserScene`
+    + the `Scene` typedef, to stand inside namespace sdfr after #include "sdfr_hlsl.h"."""
+    if os.path.exists(source):
+        with open(source) as f:
+            source = f.read()
+    L = load_library()
+    n = L.sdfr_translate_scene_hlsl(source.encode(), None, 0)
+    buf = ctypes.create_string_buffer(n)
+    L.sdfr_translate_scene_hlsl(source.encode(), buf, n)
+    return buf.value.decode()
 
 
 def strip_buffer_pixels(width, height, world, split=(0, 1)):
@@ -323,6 +350,15 @@ class SDFRenderer:
             with open(source) as f:
                 source = f.read()
         self._check(self._L.sdfr_load_scene_source(self._h, name.encode(), source.encode()))
+        return True
+
+    def initShaderHlsl(self, name, source):
+        """A scene in the reference's own dialect: the text (or path) of an .hlsl scene file with map / map_normal / map_light /
+        map_background, as Application::loadScene would substitute it into the shader (sdfr_load_scene_hlsl)."""
+        if os.path.exists(source):
+            with open(source) as f:
+                source = f.read()
+        self._check(self._L.sdfr_load_scene_hlsl(self._h, name.encode(), source.encode()))
         return True
 
     def currentScene(self):

@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdfr.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_peer.hip", "sdfr_post.hip"]
+SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_hlsl.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_peer.hip", "sdfr_post.hip"]
 GROUP_SOURCE = "sdfr_kernels_group.hip"
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-x", "hip", "-Wno-unused-result",

@@ -8,6 +8,8 @@
     python -m sdf_playground_amd.cli --parse-hlsl path/to/sdf_scene_x.hlsl      # VAR_ tags of a scene file
     python -m sdf_playground_amd.cli --scene-source sdf_playground_amd/scenes/pendulum.scene.h --out p.png
     python -m sdf_playground_amd.cli --scene-source my.scene.h --check              # compile only, no GPU
+    python -m sdf_playground_amd.cli --scene-hlsl sdf_playground_amd/scenes/pendulum.hlsl --out p.png   # a scene in the reference's dialect
+    python -m sdf_playground_amd.cli --scene-hlsl Engine/shader/scenes/sdf_scene_tree.hlsl --translate   # the generated C++
 
 --out writes the tone-mapped + bloomed LDR image (HDR::process, like the reference's window);
 --out-hdr writes the raw float32 RGBA frame as .npy.  Needs a GPU.
@@ -74,7 +76,10 @@ def main(argv=None):
     ap.add_argument("--list-scenes", action="store_true")
     ap.add_argument("--scene")
     ap.add_argument("--scene-source", metavar="FILE", help="scene compiled at run time (scenes/README.md)")
-    ap.add_argument("--check", action="store_true", help="with --scene-source: compile only, no GPU needed")
+    ap.add_argument("--scene-hlsl", metavar="FILE", help="scene in the reference's own dialect: an .hlsl scene file with map / map_normal / map_light / "
+                                                         "map_background (sdfr_load_scene_hlsl)")
+    ap.add_argument("--translate", action="store_true", help="with --scene-hlsl: print the C++ generated from the file and stop")
+    ap.add_argument("--check", action="store_true", help="with --scene-source / --scene-hlsl: compile only, no GPU needed")
     ap.add_argument("--list-vars", action="store_true")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--time", type=float, default=0.0)
@@ -106,15 +111,23 @@ def main(argv=None):
         ok, log = sp.check_scene_source(a.scene_source)
         print("ok" if ok else log)
         return 0 if ok else 1
-    if not a.scene and not a.scene_source:
-        ap.error("--scene or --scene-source is required")
+    if a.scene_hlsl and a.translate:
+        print(sp.translate_scene_hlsl(a.scene_hlsl))
+        return 0
+    if a.scene_hlsl and a.check:
+        ok, log = sp.check_scene_hlsl(a.scene_hlsl)
+        print("ok" if ok else log)
+        return 0 if ok else 1
+    if not a.scene and not a.scene_source and not a.scene_hlsl:
+        ap.error("--scene, --scene-source or --scene-hlsl is required")
     r = sp.SDFRenderer(a.device)
-    if a.scene_source:
+    if a.scene_source or a.scene_hlsl:
         import os
 
-        a.scene = os.path.basename(a.scene_source).split(".")[0]
+        path = a.scene_source or a.scene_hlsl
+        a.scene = os.path.basename(path).split(".")[0]
         try:
-            r.initShaderSource(a.scene, a.scene_source)
+            (r.initShaderSource if a.scene_source else r.initShaderHlsl)(a.scene, path)
         except sp.SdfrError as e:
             print(e, file=sys.stderr)
             return 1

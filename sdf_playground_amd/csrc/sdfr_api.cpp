@@ -4,6 +4,7 @@
 // preparation, device buffers and launches.  All pixels are produced by the HIP kernels in
 // sdfr_kernels.hip; there is no CPU rendering path.
 #include "sdfr_handle.h"
+#include "sdfr_hlsl_translate.h"
 
 #include <chrono>
 #include <cstdio>
@@ -251,6 +252,53 @@ int sdfr_check_scene_source(const char *source, const char *arch, char *log, siz
 	if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", source, slots, code, err)) rc = SDFR_ERR_COMPILE;
 	if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
 	return rc;
+}
+
+// ---- scenes in the reference's own dialect (sdfr_hlsl.h / sdfr_hlsl.cpp) ------------------------------------
+int sdfr_translate_scene_hlsl(const char *hlsl_source, char *out, size_t out_bytes)
+{
+	if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+	const std::string text = hlsl_scene_source(hlsl_source);
+	if (out && out_bytes) snprintf(out, out_bytes, "%s", text.c_str());
+	return (int)text.size() + 1;
+}
+
+int sdfr_check_scene_hlsl(const char *hlsl_source, const char *arch, char *log, size_t log_bytes)
+{
+	if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+	// the variable table comes from the tags of the ORIGINAL text (ShaderUtil.cpp:122-191); the generated class reads them
+	// through the same VAR_<name>(...) macros as any run-time scene
+	if (log && log_bytes) log[0] = 0;
+	sdfr_renderer scratch;
+	host::ShaderVariableManager vm;
+	std::vector<std::string> slots;
+	std::string err;
+	int rc = build_variable_table(&scratch, hlsl_source, vm, slots);
+	if (rc != SDFR_OK) err = scratch.error;
+	std::vector<char> code;
+	if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", hlsl_scene_source(hlsl_source), slots, code, err)) rc = SDFR_ERR_COMPILE;
+	if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
+	return rc;
+}
+
+int sdfr_load_scene_hlsl(sdfr_renderer *r, const char *name, const char *hlsl_source)
+{
+	if (!r || !name || !hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+	SDFR_HIP(hipSetDevice(r->device));
+	host::ShaderVariableManager vm;
+	std::vector<std::string> slots;
+	const int rc = build_variable_table(r, hlsl_source, vm, slots);
+	if (rc != SDFR_OK) return rc;
+	JitScene js;
+	std::string err;
+	if (!jit_compile(r->device, name, hlsl_scene_source(hlsl_source), slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
+	SDFR_HIP(hipStreamSynchronize(r->stream));
+	jit_unload(r->jit);
+	r->jit = js;
+	r->vars = vm;
+	r->scene_var_slots = slots;
+	r->scene = SDFR_SCENE_COUNT;
+	return SDFR_OK;
 }
 
 int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *source)

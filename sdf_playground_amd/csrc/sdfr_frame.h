@@ -73,6 +73,8 @@ struct SurfacePoint
 	float camera_distance;
 	vec3 right_off, bottom_off; // pixel footprint per unit of distance
 	vec3 normal;                // MaterialInput.obj_normal: the geometric normal at the hit
+	uint32_t iteration_count;   // MaterialInput.iteration_count: march iterations of the ray that hit (sdf_structs.hlsl:54-64)
+	float scene_distance;       // MaterialInput.scene_distance: the distance the march stopped at (already * inside_sign)
 };
 
 // NormalOutput of the scene ABI (sdf_structs.hlsl:39-52), preloaded by the driver (pshader_sdf.hlsl:320-323):

@@ -82,6 +82,8 @@ std::string jit_translation_unit(const std::string &scene_source, const std::vec
 {
 	std::string tu;
 	tu += "#include \"sdfr_pixel_kernel.h\"\n";
+	// a scene that came in the reference's dialect (sdfr_hlsl.cpp) needs the HLSL vocabulary
+	if (scene_source.find("hlsl::SceneAdapter") != std::string::npos) tu += "#include \"sdfr_hlsl.h\"\n";
 	tu += "namespace sdfr {\n";
 	for (size_t k = 0; k < var_slots.size(); ++k)
 		tu += "#define VAR_" + var_slots[k] + "(...) (U.scene_var[" + std::to_string(k) + "])\n";

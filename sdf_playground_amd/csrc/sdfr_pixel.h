@@ -217,10 +217,39 @@ SDF_HD NormalOut scene_normal(const FrameU &U, vec3 hit_pos, vec3 dir, float cam
 		sp.right_off = right_ray;
 		sp.bottom_off = bottom_ray;
 		sp.normal = V3s(0.f);
+		sp.iteration_count = 0u;
+		sp.scene_distance = 0.f;
 		SceneNormal<Scene>::call(U, sp, no);
 	}
 	return no;
 }
+
+// ---- the scene's map_light as ONE call per hit (pshader_sdf.hlsl:505-516) -----------------------------
+// The scenes compiled ahead of time answer `light(U, i, L)` slot by slot and `ambient()` without arguments: their lights do
+// not depend on the hit point, and unused slots cost nothing.  A scene may instead declare
+//   static SDF_HD void lights(const FrameU &U, const SurfacePoint &sp, Light L[SDFR_MAX_LIGHTS], bool used[SDFR_MAX_LIGHTS], float &ambient)
+// -- the reference's own shape: map_light(geometry, inout LightOutput[8], inout ambient), called once per lit hit with
+// `used` all false and `ambient` 0.075 (what scenes in the reference's dialect get, sdfr_hlsl.h).
+template <class Scene, class = void>
+struct SceneLights
+{
+	static constexpr bool available = false;
+	static SDF_HD void call(const FrameU &, const SurfacePoint &, Light *, bool *, float &) {}
+};
+template <class Scene>
+struct SceneLights<Scene, typename VoidOfN<decltype(&Scene::lights)>::type>
+{
+	static constexpr bool available = true;
+	static SDF_HD void call(const FrameU &U, const SurfacePoint &sp, Light *L, bool *used, float &ambient) { Scene::lights(U, sp, L, used, ambient); }
+};
+template <class Scene, bool HasLights = SceneLights<Scene>::available>
+struct SceneAmbient { static SDF_HD float get() { return Scene::ambient(); } };
+template <class Scene>
+struct SceneAmbient<Scene, true> { static SDF_HD float get() { return 0.075f; } };
+template <class Scene, bool HasLights = SceneLights<Scene>::available>
+struct SceneLightSlot { static SDF_HD bool get(const FrameU &U, int i, Light &L) { return Scene::light(U, i, L); } };
+template <class Scene>
+struct SceneLightSlot<Scene, true> { static SDF_HD bool get(const FrameU &, int, Light &) { return false; } };
 
 // ---- results handed from marching to shading ---------------------------------------------------
 struct HitInfo
@@ -324,6 +353,8 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 	sp.right_off = px.right_ray;
 	sp.bottom_off = px.bottom_ray;
 	sp.normal = hit.normal;
+	sp.iteration_count = hit.iter;
+	sp.scene_distance = hit.d;
 
 	Material m = default_material(U, hit.pos);
 	map_material<Scene, DBG>(U, F, sp, m);
@@ -441,7 +472,23 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 
 		if (use_light)
 		{
-			const float ambient = Scene::ambient(); // map_light may override the default 0.075
+			float ambient = SceneAmbient<Scene>::get(); // map_light may override the default 0.075
+			// a scene in the reference's own shape fills the whole light table in one call (SceneLights)
+			Light table[SceneLights<Scene>::available ? SDFR_MAX_LIGHTS : 1];
+			bool table_used[SceneLights<Scene>::available ? SDFR_MAX_LIGHTS : 1];
+			if (SceneLights<Scene>::available)
+			{
+				for (int i = 0; i < SDFR_MAX_LIGHTS; ++i)
+				{
+					table_used[i] = false;
+					table[i].pos = V3s(0.f);
+					table[i].directional = false;
+					table[i].extend = 0.f;
+					table[i].color = V3s(0.f);
+					table[i].falloff = 0.f;
+				}
+				SceneLights<Scene>::call(U, sp, table, table_used, ambient);
+			}
 			float move = max1(U.shadow_eps, hit.sample_dist) + max1(0.f, -hit.d);
 			vec3 lit_pos = mad(n, move, hit.pos);
 			const float alpha = sat1(m.diffuse.w);
@@ -449,7 +496,12 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 			for (int i = 0; i < U.light_count; ++i)
 			{
 				Light L;
-				bool used = Scene::light(U, i, L);
+				bool used = SceneLightSlot<Scene>::get(U, i, L);
+				if (SceneLights<Scene>::available)
+				{
+					L = table[i];
+					used = table_used[i];
+				}
 				if (i >= 1 && i <= U.extension_lights) // extension: orbiting point lights (sdfr_frame.h)
 				{
 					const float *E = U.ext_light[i - 1];
