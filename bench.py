@@ -709,11 +709,18 @@ def run(a, world):
     # strips render without the gather
     rays_per_frame = []
     kernel_ms = []
+    xfer_ms, xfer_bytes = [], 0
     scratch = None
     for k in range(min(SWEEP, a.steps)):
         hs = step(k)
         sts = [h_.getStats() for h_ in hs]
         rays_per_frame.append(sum(int(st.rays) for st in sts))
+        if distributed and comm is not None:
+            # the transfer of this frame on the handle's comm stream (sdfr_get_timings: "gather transfer <bytes> B")
+            for name, ms in hs[0].getTimings().items():
+                if name.startswith("gather transfer"):
+                    xfer_ms.append(ms)
+                    xfer_bytes = int(name.split()[2])
         if distributed and (comm is not None or peer_copy):
             if scratch is None:
                 scratch = torch.empty((sp.strip_buffer_bytes(W, H, world, wire_fmt, split),), dtype=torch.uint8, device="cuda")
@@ -728,15 +735,26 @@ def run(a, world):
     rays_t = torch.tensor([my_rays], dtype=torch.float64, device=ctl)
     per_rank = None
     if distributed:
-        every = [torch.zeros(2, dtype=torch.float64, device=ctl) for _ in range(world)]
-        dist.all_gather(every, torch.tensor([my_rays, elapsed], dtype=torch.float64, device=ctl))
-        per_rank = [{"rank": i, "rays": float(v[0].item()), "seconds": float(v[1].item())} for i, v in enumerate(every)]
+        every = [torch.zeros(5, dtype=torch.float64, device=ctl) for _ in range(world)]
+        mean_xfer = float(np.mean(xfer_ms)) if xfer_ms else 0.0
+        dist.all_gather(every, torch.tensor([my_rays, elapsed, float(np.mean(kernel_ms)), mean_xfer, float(xfer_bytes)], dtype=torch.float64, device=ctl))
+        per_rank = []
+        for i, v in enumerate(every):
+            e = {"rank": i, "rays": float(v[0].item()), "seconds": float(v[1].item()), "strips_kernel_ms": float(v[2].item())}
+            if v[3].item() > 0:
+                # a peer sends its strips over its one link to rank 0; rank 0 receives world - 1 messages at once, one per link
+                links = (world - 1) if i == 0 else 1
+                e.update({"transfer_ms": float(v[3].item()), "transfer_bytes": int(v[4].item()),
+                          "GBps_per_link": float(v[4].item()) / links / (v[3].item() * 1e-3) / 1e9})
+            per_rank.append(e)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_rays = float(rays_t.item())
 
     verified = None
+    if world > 1:
+        a.verify = True   # an N-rank line certifies its own image: one more frame, gathered and compared with a direct render on rank 0
     if a.verify and rank == 0:
         last = a.steps - 1
         step(last)
@@ -753,6 +771,41 @@ def run(a, world):
     elif a.verify and distributed:
         step(a.steps - 1)  # every rank takes part in the extra gather
         torch.cuda.synchronize()
+
+    scaling_base = None
+    if distributed and world > 1:
+        # what the driver's scaling ratio should be read against: ONE GPU rendering whole frames the way a rank renders its
+        # share -- `depth` frames in flight on as many handles and streams, one wave per tile, no gather -- measured by rank 0
+        # in this very job while the others wait (the N = 1 headline keeps one frame in flight: its kernel times mean what
+        # they say, and it pays the tail of every frame)
+        fence()
+        if rank == 0:
+            solo = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(depth)]
+
+            def solo_step(s):
+                h_ = rr[s % depth]
+                h_.setParameters(cameras[s % SWEEP][1])
+                h_.setCamera(cameras[s % SWEEP][0])
+                h_.render(None, W, H, out=solo[s % depth])
+
+            for s in range(depth + 1):
+                solo_step(s)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for s in range(a.steps):
+                solo_step(s)
+            torch.cuda.synchronize()
+            ms_b = (time.perf_counter() - tb) / a.steps * 1e3
+            rays_b = 0
+            for s in range(min(SWEEP, a.steps)):
+                solo_step(s)
+                rays_b += int(rr[s % depth].getStats().rays)
+            rays_b = rays_b / min(SWEEP, a.steps)
+            scaling_base = {"n_gpus": 1, "frames_in_flight": depth, "ms_per_step": ms_b, "value": rays_b / (ms_b * 1e-3) / 1e6, "unit": "Mrays/s",
+                            "note": "rank 0 alone, whole frames, the same %d frames in flight and launch mode as the N-rank pipeline, no gather: "
+                                    "value / scaling_base.value compares like with like" % depth}
+            del solo
+        fence()
 
     if rank == 0:
         census = load_census(a.config)
@@ -787,7 +840,13 @@ def run(a, world):
                 "frames_in_flight": depth,
                 "strip_calibration": calibration,
                 "per_rank": per_rank,
+                # true whenever the line is NOT what `--gpus N` is meant to measure: the library's RCCL gather could not be used
+                # (fallback), or a rehearsal / experimental transport was asked for
+                "degraded": bool(comm is None),
             })
+            if scaling_base is not None:
+                out["scaling_base"] = scaling_base
+                out["speedup_vs_scaling_base"] = out["value"] / scaling_base["value"]
         # roofline of the dominant kernel (k_pixel, the only kernel of the pixel schedule), this rank's
         # launch.  Kernel duration: HIP events on the launch stream -- N = 1: the pairs recorded around
         # every step of the timed region (a step launches k_pixel + the few-us counter fold and nothing

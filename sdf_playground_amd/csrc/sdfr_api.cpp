@@ -167,9 +167,12 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipFree(r->d_post_flags);
 	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
 	(void)sdfr_peer_region_close(r);
+	if (r->peer_status) (void)hipHostFree(r->peer_status);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
+	for (hipEvent_t e : r->ev_xfer)
+		if (e) (void)hipEventDestroy(e);
 	(void)hipEventDestroy(r->ev_begin);
 	(void)hipEventDestroy(r->ev_end);
 	for (hipEvent_t e : r->ev_post) (void)hipEventDestroy(e);
@@ -873,6 +876,17 @@ int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity)
 			snprintf(nm, sizeof nm, "draw: shade %d", i);
 			put(nm, b);
 		}
+	}
+	if (r->have_render && r->have_xfer)
+	{
+		// the last sdfr_render_gather's transfer on the comm stream: rank 0 receives world - 1 messages at once (one per link),
+		// a peer sends one; the bytes ride in the name so that a caller can turn the time into a rate
+		SDFR_HIP(hipEventSynchronize(r->ev_xfer[1]));
+		float t = 0.f;
+		SDFR_HIP(hipEventElapsedTime(&t, r->ev_xfer[0], r->ev_xfer[1]));
+		char nm[32];
+		snprintf(nm, sizeof nm, "gather transfer %zu B", r->xfer_bytes);
+		put(nm, t);
 	}
 	if (r->have_post)
 	{

@@ -187,6 +187,8 @@ int sdfr::gather_prepare_streams(sdfr_renderer *r)
 	}
 	if (!r->ev_strips) SDFR_HIP(hipEventCreateWithFlags(&r->ev_strips, hipEventDisableTiming));
 	if (!r->ev_gathered) SDFR_HIP(hipEventCreateWithFlags(&r->ev_gathered, hipEventDisableTiming));
+	for (int k = 0; k < 2; ++k)
+		if (!r->ev_xfer[k]) SDFR_HIP(hipEventCreate(&r->ev_xfer[k]));
 	return SDFR_OK;
 }
 
@@ -571,15 +573,20 @@ int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, vo
 	comm_remember_renderer(c, r);
 	rc = gather_render(r, c, g);
 	if (rc != SDFR_OK) return rc;
+	r->have_xfer = false;
 	if (g.world > 1 && g.rank_bytes)
 	{
 		Rccl &n = rccl();
+		SDFR_HIP(hipEventRecord(r->ev_xfer[0], r->comm_stream));
 		ncclResult_t nrc = n.group_start();
 		if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupStart"), c->error);
 		rc = gather_transfer(r, c, g);
 		nrc = n.group_end();
 		if (rc != SDFR_OK) return rc;
 		if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupEnd"), c->error);
+		SDFR_HIP(hipEventRecord(r->ev_xfer[1], r->comm_stream));
+		r->have_xfer = true;
+		r->xfer_bytes = c->rank == 0 ? (size_t)(g.world - 1) * g.rank_bytes : g.rank_bytes;
 	}
 	return gather_finish(r, c, g, root_image);
 }

@@ -58,6 +58,9 @@ struct sdfr_renderer
 	// that the root's private strips render while the peers' strips travel
 	hipStream_t comm_stream = nullptr;
 	hipEvent_t ev_strips = nullptr, ev_gathered = nullptr;
+	hipEvent_t ev_xfer[2] = {nullptr, nullptr}; // around the last gather's transfer on the comm stream ("gather transfer", sdfr_get_timings)
+	bool have_xfer = false;
+	size_t xfer_bytes = 0;                      // bytes this rank sent (peers) or received (rank 0) in that transfer
 	void *d_wire = nullptr;    // this rank's compact strips; on the root: world x that, slot 0 = its own
 	size_t wire_bytes = 0;
 	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
@@ -70,6 +73,7 @@ struct sdfr_renderer
 	int peer_world = 0;
 	bool peer_owner = false;
 	uint32_t peer_frame = 0;        // frames gathered through this region so far
+	uint32_t *peer_status = nullptr, *d_peer_status = nullptr; // this rank's "a wait gave up" word: mapped host memory, host / device view
 };
 
 static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)

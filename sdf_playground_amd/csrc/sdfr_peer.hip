@@ -9,9 +9,14 @@
 //            arrived[rank] with system scope
 //   rank 0   a one-wave kernel waits until every arrived[p] has reached the frame number, k_assemble scatters
 //            the slots into the image, a one-thread kernel stores the frame number into `released`
-// Waits are bounded (2 s of the 100-MHz clock): a rank that never arrives sets `timed_out` instead of hanging
-// the GPU; sdfr_peer_region_status reports it.  Same strip layout, wire formats, private strips and counters as
-// sdfr_render_gather (sdfr_comm.cpp); the reference has no counterpart (one adapter, Graphics.cpp:34).
+// Waits are bounded (2 s of the 100-MHz clock): a rank that never arrives makes the wait give up instead of hanging
+// the GPU.  A wait that gave up says so in a status word of this rank's own (host memory the GPU writes through a
+// mapping), and what follows it on the stream looks at that word first: the copy into rank 0's slot and rank 0's
+// assembly are SKIPPED (no torn frame: a peer must not write a slot rank 0 may still be reading), the next
+// sdfr_render_gather_peer refuses with SDFR_ERR_COMM, sdfr_peer_region_status reports it, and only a new region
+// (create / open) clears it.  The flag words other devices write while a kernel polls them are fine-grained memory.
+// Same strip layout, wire formats, private strips and counters as sdfr_render_gather (sdfr_comm.cpp); the reference
+// has no counterpart (one adapter, Graphics.cpp:34).
 #include "sdfr_handle.h"
 
 #include <cstring>
@@ -20,7 +25,7 @@ using namespace sdfr;
 
 namespace {
 
-enum { FLAG_ARRIVED = 0, FLAG_RELEASED = 64, FLAG_TIMED_OUT = 65, FLAG_WORDS = 128 };
+enum { FLAG_ARRIVED = 0, FLAG_RELEASED = 64, FLAG_WORDS = 128 };
 #define PEER_WAIT_TICKS 200000000ull // 2 s
 
 struct Descriptor
@@ -32,27 +37,40 @@ struct Descriptor
 };
 static_assert(sizeof(Descriptor) <= SDFR_PEER_REGION_BYTES, "SDFR_PEER_REGION_BYTES");
 
-__global__ void k_peer_signal(uint32_t *flag, uint32_t value)
-{
-	__threadfence_system();
-	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// lanes 0 .. n-1 each wait for flags[lane * stride] >= value; every wave of the grid reaches the end
-__global__ void k_peer_wait(uint32_t *flags, int first, int n, uint32_t value, uint32_t *timed_out)
+// lanes 0 .. n-1 each wait for flags[first + lane] >= value; every wave of the grid reaches the end.  A wait that gives
+// up (or finds that an earlier one has) leaves the frame number in *status: what follows on the stream is skipped.
+__global__ void k_peer_wait(uint32_t *flags, int first, int n, uint32_t value, uint32_t *status, uint32_t frame)
 {
 	const int lane = (int)threadIdx.x;
 	if (lane >= n) return;
+	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 	while (__hip_atomic_load(flags + first + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value)
 	{
 		if (__builtin_amdgcn_s_memrealtime() - t0 > PEER_WAIT_TICKS)
 		{
-			__hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(status, frame ? frame : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			return;
 		}
 		__builtin_amdgcn_s_sleep(32);
 	}
+}
+
+// a peer's strips into its slot of rank 0's buffer, over the link -- unless a wait gave up (see the head of the file)
+__global__ __launch_bounds__(256) void k_peer_copy(uint32_t *dst, const uint32_t *src, size_t words, const uint32_t *status)
+{
+	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	const size_t stride = (size_t)gridDim.x * blockDim.x, quads = words / 4;
+	const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+	uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) d4[i] = s4[i];
+	for (size_t i = quads * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) dst[i] = src[i];
+}
+__global__ void k_peer_signal_unless(uint32_t *flag, uint32_t value, const uint32_t *status)
+{
+	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	__threadfence_system();
+	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void region_forget(sdfr_renderer *r)
@@ -63,6 +81,32 @@ void region_forget(sdfr_renderer *r)
 	r->peer_world = 0;
 	r->peer_owner = false;
 	r->peer_frame = 0;
+}
+
+// this rank's status word: host memory the GPU writes through a mapping, so the host reads it without a synchronisation
+int status_word(sdfr_renderer *r)
+{
+	if (!r->peer_status)
+	{
+		SDFR_HIP(hipHostMalloc((void **)&r->peer_status, 64, hipHostMallocMapped));
+		SDFR_HIP(hipHostGetDevicePointer((void **)&r->d_peer_status, r->peer_status, 0));
+	}
+	*r->peer_status = 0u; // a new region starts clean
+	return SDFR_OK;
+}
+
+// the flag words are written by other devices while a kernel of this one polls them: fine-grained where the runtime has it
+hipError_t flags_alloc(uint32_t **flags, bool *fine)
+{
+	*fine = true;
+	hipError_t e = hipExtMallocWithFlags((void **)flags, FLAG_WORDS * sizeof(uint32_t), hipDeviceMallocFinegrained);
+	if (e != hipSuccess)
+	{
+		(void)hipGetLastError();
+		*fine = false;
+		e = hipMalloc((void **)flags, FLAG_WORDS * sizeof(uint32_t));
+	}
+	return e;
 }
 
 } // namespace
@@ -95,15 +139,31 @@ int sdfr_peer_region_create(sdfr_renderer *r, size_t capacity_bytes, int world, 
 	if (!r || !descriptor_out || capacity_bytes == 0 || world < 1 || world > 64) return SDFR_ERR_INVALID_ARGUMENT;
 	(void)sdfr_peer_region_close(r);
 	SDFR_HIP(hipSetDevice(r->device));
+	int src = status_word(r);
+	if (src != SDFR_OK) return src;
 	void *buffer = nullptr;
 	uint32_t *flags = nullptr;
 	SDFR_HIP(hipMalloc(&buffer, capacity_bytes));
-	hipError_t e = hipMalloc((void **)&flags, FLAG_WORDS * sizeof(uint32_t));
+	bool fine = false;
+	hipError_t e = flags_alloc(&flags, &fine);
 	if (e == hipSuccess) e = hipMemset(flags, 0, FLAG_WORDS * sizeof(uint32_t));
 	Descriptor d;
 	memset(&d, 0, sizeof d);
 	if (e == hipSuccess) e = hipIpcGetMemHandle(&d.buffer, buffer);
 	if (e == hipSuccess) e = hipIpcGetMemHandle(&d.flags, flags);
+	if (e != hipSuccess && fine && flags)
+	{
+		// a runtime that cannot export fine-grained memory: ordinary device memory, as before
+		(void)hipGetLastError();
+		(void)hipFree(flags);
+		flags = nullptr;
+		fine = false;
+		e = hipMalloc((void **)&flags, FLAG_WORDS * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMemset(flags, 0, FLAG_WORDS * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipIpcGetMemHandle(&d.buffer, buffer);
+		if (e == hipSuccess) e = hipIpcGetMemHandle(&d.flags, flags);
+	}
+	d.reserved = fine ? 1u : 0u;
 	if (e != hipSuccess)
 	{
 		(void)hipFree(buffer);
@@ -133,6 +193,8 @@ int sdfr_peer_region_open(sdfr_renderer *r, const void *descriptor)
 	if (d.magic != 0x53444652u || d.world < 1 || d.world > 64 || d.capacity == 0) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "not a peer-region descriptor");
 	(void)sdfr_peer_region_close(r);
 	SDFR_HIP(hipSetDevice(r->device));
+	int src = status_word(r);
+	if (src != SDFR_OK) return src;
 	void *buffer = nullptr, *flags = nullptr;
 	SDFR_HIP(hipIpcOpenMemHandle(&buffer, d.buffer, hipIpcMemLazyEnablePeerAccess));
 	hipError_t e = hipIpcOpenMemHandle(&flags, d.flags, hipIpcMemLazyEnablePeerAccess);
@@ -157,9 +219,10 @@ int sdfr_peer_region_status(sdfr_renderer *r)
 	SDFR_HIP(hipSetDevice(r->device));
 	SDFR_HIP(hipStreamSynchronize(r->stream));
 	if (r->comm_stream) SDFR_HIP(hipStreamSynchronize(r->comm_stream));
-	uint32_t timed_out = 0;
-	SDFR_HIP(hipMemcpy(&timed_out, r->peer_flags + FLAG_TIMED_OUT, sizeof timed_out, hipMemcpyDeviceToHost));
-	if (timed_out) return fail(r, SDFR_ERR_COMM, "a wait of the peer-copy gather gave up: some rank did not arrive (or did not release the region) within 2 s");
+	const uint32_t gave_up = r->peer_status ? *(volatile uint32_t *)r->peer_status : 0u;
+	if (gave_up)
+		return fail(r, SDFR_ERR_COMM, "a wait of the peer-copy gather gave up in frame " + std::to_string(gave_up) +
+									  ": some rank did not arrive (or did not release the region) within 2 s; that frame's copy and assembly were skipped");
 	return SDFR_OK;
 }
 
@@ -180,6 +243,10 @@ int sdfr_render_gather_peer(sdfr_renderer *r, int rank, int world, int width, in
 	const size_t nb = (size_t)nb64;
 	if (nb * (size_t)world > r->peer_capacity) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "the peer region is too small for this frame");
 
+	// a wait that gave up earlier (no synchronisation: the word is host memory): no further frame through this region
+	if (r->peer_status && *(volatile uint32_t *)r->peer_status)
+		return fail(r, SDFR_ERR_COMM, "the peer region is stale: a wait gave up in frame " + std::to_string(*(volatile uint32_t *)r->peer_status) +
+									  " (a rank did not arrive within 2 s); close it and make a new one");
 	int rc = gather_prepare_streams(r);
 	if (rc != SDFR_OK) return rc;
 	const uint32_t frame = ++r->peer_frame;
@@ -216,20 +283,23 @@ int sdfr_render_gather_peer(sdfr_renderer *r, int rank, int world, int width, in
 		if (nb && world > 1)
 		{
 			// the region is free once rank 0 has assembled the frame before out of it
-			hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_RELEASED, 1, frame - 1u, flags + FLAG_TIMED_OUT);
-			SDFR_HIP(hipMemcpyAsync((char *)r->peer_buffer + (size_t)rank * nb, r->d_wire, nb, hipMemcpyDeviceToDevice, r->comm_stream));
-			hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_ARRIVED + rank, frame);
+			hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_RELEASED, 1, frame - 1u, r->d_peer_status, frame);
+			// (a kernel, not hipMemcpyAsync: a copy engine cannot be told to skip a frame whose wait gave up)
+			hipLaunchKernelGGL(k_peer_copy, dim3(256), dim3(256), 0, r->comm_stream, reinterpret_cast<uint32_t *>((char *)r->peer_buffer + (size_t)rank * nb),
+				reinterpret_cast<const uint32_t *>(r->d_wire), nb / 4, r->d_peer_status);
+			hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_ARRIVED + rank, frame, r->d_peer_status);
 		}
 	}
 	else
 	{
 		if (nb)
 		{
-			if (world > 1) hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_ARRIVED + 1, world - 1, frame, flags + FLAG_TIMED_OUT);
-			hipError_t e = launch_assemble_strips(width, height, world, r->peer_buffer, root_image, wire_format, r->priv_count, r->priv_period, r->comm_stream);
+			if (world > 1) hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_ARRIVED + 1, world - 1, frame, r->d_peer_status, frame);
+			hipError_t e = launch_assemble_strips(width, height, world, r->peer_buffer, root_image, wire_format, r->priv_count, r->priv_period, r->comm_stream,
+				r->d_peer_status);
 			if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
 		}
-		if (world > 1) hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_RELEASED, frame);
+		if (world > 1) hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_RELEASED, frame, r->d_peer_status);
 		if (r->priv_count > 0)
 		{
 			r->caller_times = true;

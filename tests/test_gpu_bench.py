@@ -52,6 +52,7 @@ def test_bench_strip_pipeline_assembles_the_same_image(transport, wire):
     assert d["verified"] is True
     assert d["config"]["parallelism"] == "strips1" and d["scaling"] == "strong" and d["n_gpus"] == 1
     assert d["config"]["transport"].startswith("sdfr_render_gather" if transport == "rccl" else "torch.distributed.gather: torch")
+    assert d["config"]["degraded"] is (transport != "rccl")
     assert ("RGB16F" in d["config"]["wire_format"]) == (wire == "f16")
     cal = d["config"]["strip_calibration"]
     assert 0 <= cal["private_strips_of_16"] < 16 and all(v > 0 for v in cal["ms_per_frame_by_private_strips"].values())
@@ -82,6 +83,11 @@ def test_bench_n_ranks_rehearsed_on_one_gpu(ranks, extra):
     assembles; its image must equal a direct render bit for bit and the ranks' ray counters must add up to the frame's."""
     d = _run(["--gpus", str(ranks), "--transport", "gloo"] + extra)
     assert d["verified"] is True and d["n_gpus"] == ranks and d["config"]["parallelism"] == "strips%d" % ranks
+    # an N-rank line certifies itself: verified without --verify being asked for (the helper passes it anyway), says that this
+    # transport is not the one a result would use, and carries an N = 1 figure at the same frames in flight
+    assert d["config"]["degraded"] is True and d["scaling_base"]["n_gpus"] == 1 and d["scaling_base"]["value"] > 0
+    assert d["scaling_base"]["frames_in_flight"] == d["config"]["frames_in_flight"] and d["speedup_vs_scaling_base"] > 0
+    assert all(p["strips_kernel_ms"] > 0 for p in d["config"]["per_rank"])
     per_rank = d["config"]["per_rank"]
     assert [p["rank"] for p in per_rank] == list(range(ranks)) and all(p["rays"] > 0 for p in per_rank)
     total = sum(p["rays"] for p in per_rank)

@@ -204,8 +204,20 @@ def test_peer_copy_gather_world_one_and_a_peer_that_never_arrives(scene_renderer
     with pytest.raises(sp.SdfrError):
         r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)  # the region was made for a world of one
     r.peerRegionCreate(2 * sp.strip_buffer_bytes(W, H, 2, sp.STRIP_RGB16F_A8), 2)
+    out.fill_(-7.0)
     r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)      # nobody plays rank 1
     with pytest.raises(sp.SdfrError) as e:
         r.peerRegionStatus()
     assert e.value.code == -8 and "did not arrive" in str(e.value)
+    # the frame whose wait gave up was NOT assembled out of half-filled slots (round-2 review: no torn frames) ...
+    assert bool((out == -7.0).all())
+    # ... the region is stale from then on: the next frame is refused at once, without a synchronisation ...
+    with pytest.raises(sp.SdfrError) as e:
+        r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)
+    assert e.value.code == -8 and "stale" in str(e.value)
+    # ... and a new region starts clean
+    r.peerRegionCreate(sp.strip_buffer_bytes(W, H, 1, sp.STRIP_RGB16F_A8), 1)
+    r.renderGatherPeer(0, 1, W, H, out=out, fmt=sp.RGBA16F)
+    r.peerRegionStatus()
+    assert torch.equal(out.view(torch.int16), full16.view(torch.int16))
     r.peerRegionClose()
