@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
+def _run(extra, steps=7):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "328", "--height", "205", "--steps", "7", "--warmup", "2",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "328", "--height", "205", "--steps", str(steps), "--warmup", "2",
                         "--no-cpu-baseline", "--verify"] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -24,7 +24,7 @@ def _run(extra):
 
 def test_bench_extra_passes_and_steady_state():
     """N = 1 extras: every step marched, the reference's own limits, and a sweep looped for --min-seconds"""
-    d = _run(["--min-seconds", "0.3", "--no-second-pass"])
+    d = _run(["--min-seconds", "0.3", "--no-second-pass"], steps=16)  # the extra passes cover the 16 sweep frames: so does this run
     ex, rl, st = d["exact_steps"], d["reference_limits"], d["steady"]
     assert ex["value"] > 0 and rl["value"] > 0 and st["value"] > 0 and st["seconds"] >= 0.3 and st["steps"] % 16 == 0
     # same frames: the rays do not depend on the shortcuts; marching every step costs evaluations
