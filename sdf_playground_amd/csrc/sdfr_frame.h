@@ -154,6 +154,21 @@ SDF_HD uint32_t private_strip_count(uint32_t strips, int priv_count, int priv_pe
 	return (strips / (uint32_t)priv_period) * (uint32_t)priv_count + (rem < (uint32_t)priv_count ? rem : (uint32_t)priv_count);
 }
 
+// Everything a launch of the pixel kernel is given, as ONE by-value kernel argument: the frame uniforms first.
+struct PixelKernelArgs
+{
+	FrameU U;
+	RowMap rm;
+	uint32_t n_work;
+	int format;
+	void *out;
+	uint32_t *pixel_stats;
+	RenderTotals *partials, *totals;
+	float *ray_queue;
+	unsigned long cap; // pixels the ray queue is allocated for (size_t)
+	uint32_t *tile_cursors;
+};
+
 enum { FORMAT_RGBA32F = 0, FORMAT_RGBA16F = 1, FORMAT_STRIP_RGB32F_A8 = 2, FORMAT_STRIP_RGB16F_A8 = 3 };
 
 } // namespace sdfr

@@ -91,12 +91,8 @@ std::string jit_translation_unit(const std::string &scene_source, const std::vec
 	tu += scene_source;
 	tu += "\n#line 1 \"sdfr_jit_kernels\"\n";
 	tu += "extern \"C\" __global__ void sdfr_jit_prepare(FrameU *U) { if (blockIdx.x == 0 && threadIdx.x == 0) Scene::prepare(*U); }\n";
-	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
-		  "{ pixel_kernel<Scene, false>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
-	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel_debug(FrameU U, RowMap rm, uint32_t n_work, void *out, int format,\n"
-		  "\tuint32_t *pixel_stats, RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)\n"
-		  "{ pixel_kernel<Scene, true>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors); }\n";
+	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel(PixelKernelArgs args) { pixel_kernel<Scene, false>(args); }\n";
+	tu += "extern \"C\" __global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void sdfr_jit_pixel_debug(PixelKernelArgs args) { pixel_kernel<Scene, true>(args); }\n";
 	tu += "} // namespace sdfr\n";
 	return tu;
 }
@@ -209,14 +205,21 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, false); // a run-time scene: one wave per tile unless asked otherwise
 	if (mode.blocks_per_cu > 0 && mode.blocks_per_cu < per_cu) per_cu = mode.blocks_per_cu;
 	const uint32_t blocks = pixel_launch_blocks(mode, (n_work + bt - 1u) / bt, (uint32_t)(device_cu_count(device) * per_cu));
-	FrameU frame = U;
-	RowMap rows = rm;
-	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
-	float *queue = ws.ray_queue;
-	size_t cap = ws.capacity;
+	PixelKernelArgs pk;
+	pk.U = U;
+	pk.rm = rm;
+	pk.rm.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
+	pk.n_work = n_work;
+	pk.format = format;
+	pk.out = out;
+	pk.pixel_stats = pixel_stats;
+	pk.partials = ws.partials;
+	pk.totals = totals;
+	pk.ray_queue = ws.ray_queue;
+	pk.cap = ws.capacity;
+	pk.tile_cursors = mode.persistent ? ws.tile_cursors : nullptr;
 	RenderTotals *partials = ws.partials;
-	uint32_t *cursors = mode.persistent ? ws.tile_cursors : nullptr;
-	void *args[] = {&frame, &rows, &n_work, &out, &format, &pixel_stats, &partials, &totals, &queue, &cap, &cursors};
+	void *args[] = {&pk};
 	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;

@@ -24,10 +24,9 @@ static uint32_t work_items(const FrameU &U, const RowMap &rm) { return launch_wo
 // PIXEL schedule (body: sdfr_pixel_kernel.h)
 // =================================================================================================
 template <class Scene, bool DBG>
-__global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void k_pixel(FrameU U, RowMap rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)
+__global__ SDFR_PIXEL_KERNEL_ATTRS(Scene) void k_pixel(PixelKernelArgs args)
 {
-	pixel_kernel<Scene, DBG>(U, rm, n_work, out, format, pixel_stats, partials, totals, ray_queue, cap, tile_cursors);
+	pixel_kernel<Scene, DBG>(args);
 }
 
 // =================================================================================================
@@ -320,8 +319,19 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	const uint32_t blocks = pixel_launch_blocks(mode, tiles_blocks, (uint32_t)device_cu_count(device) * per_cu);
 	RowMap rows = rm;
 	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
-	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, U, rows, n_work, out, format, pixel_stats, ws.partials, totals,
-		ws.ray_queue, ws.capacity, mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr);
+	PixelKernelArgs args;
+	args.U = U;
+	args.rm = rows;
+	args.n_work = n_work;
+	args.format = format;
+	args.out = out;
+	args.pixel_stats = pixel_stats;
+	args.partials = ws.partials;
+	args.totals = totals;
+	args.ray_queue = ws.ray_queue;
+	args.cap = ws.capacity;
+	args.tile_cursors = mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr;
+	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, args);
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
 	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? tiles_blocks / tiles_x : 0u, (unsigned long long)n_work);
 }

@@ -402,9 +402,29 @@ struct TileQueue
 // body of the pixel kernel; the __global__ wrappers are k_pixel (scenes compiled ahead of time,
 // sdfr_kernels_group.hip) and the extern "C" kernels sdfr_jit.cpp generates around a run-time scene
 template <class Scene, bool DBG>
-__device__ __forceinline__ void pixel_kernel(const FrameU &U, const RowMap &rm, uint32_t n_work, void *out, int format, uint32_t *pixel_stats,
-	RenderTotals *partials, RenderTotals *totals, float *ray_queue, size_t cap, uint32_t *tile_cursors)
+__device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_value)
 {
+	// The argument block is the kernarg segment.  Read through the by-value parameter, the compiler loads every field it
+	// will ever need at the kernel's entry and keeps it for the whole persistent tile loop: scalar registers run out (82 of
+	// them spilled to vector lanes on the labyrinth kernel), which costs vector registers, which spill to scratch -- 30
+	// dwords per lane, written once per wave, 150 MB of HBM traffic per 4K frame with waves that retire.  Read through
+	// THIS pointer -- the same memory, constant address space, so still scalar loads, but laundered through an empty asm so
+	// that the compiler no longer knows up front that it may be dereferenced -- a field is loaded where its code runs.
+	typedef const PixelKernelArgs __attribute__((address_space(4))) *ArgsPtr;
+	ArgsPtr args_ptr = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(args_ptr));
+	(void)args_by_value;
+	const PixelKernelArgs &A = *(const PixelKernelArgs *)args_ptr;
+	const FrameU &U = A.U;
+	const RowMap &rm = A.rm;
+	const uint32_t n_work = A.n_work;
+	void *const out = A.out;
+	const int format = A.format;
+	uint32_t *const pixel_stats = A.pixel_stats;
+	RenderTotals *const partials = A.partials, *const totals = A.totals;
+	float *const ray_queue = A.ray_queue;
+	const size_t cap = A.cap;
+	uint32_t *const tile_cursors = A.tile_cursors;
 	// the fold kernel that follows adds into the totals: clear them here (kernel boundary = ordering)
 	if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<unsigned long long *>(totals)[threadIdx.x] = 0ull;
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
