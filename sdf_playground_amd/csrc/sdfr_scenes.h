@@ -174,7 +174,7 @@ struct SceneCubeSea
 struct SceneLabyrinth
 {
 	static const char *name() { return "labyrinth"; }
-	static constexpr int waves_per_simd = 6; // configuration 3, final kernels of round 2: 1.35 (4) / 1.31 (5) / 1.28 (6) / 1.32 (7) ms, two runs each; before the step shortcuts 5 was ahead of 6 by 3 %: the choice follows the code (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 7; // configuration 3, round 3 (argument block read on demand: 16 spilled registers instead of 30), one session: 1.247 (5) / 1.234 (6) / 1.226 (7) / 1.254 (8) ms; round 2 had 6 ahead of 7 by 3 % (profiles/r03_launch_experiments.txt)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
@@ -267,6 +267,12 @@ struct SceneLabyrinth
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
 		const vec3 wp = fold(p);
 		d = min1(d, walls(wp));
+		// One test before the two: both bounding balls (vase: centres (7 | 9, 1.2, 3), r 1.51; torch: (5.2, 2.9, 3), r 0.91) lie in
+		// the box x >= 4.29, y <= 3.81, |z - 3| <= 1.51 of the folded cell; a point whose distance to that box along one axis is
+		// not below the running minimum is at least radius + minimum from both centres, i.e. both tests below would skip
+		// anyway (0.01 more of slack here, so the implication survives rounding).  Four instructions instead of eighteen on
+		// most steps of most rays.
+		if (max1(max1(4.28f - wp.x, wp.y - 3.82f), abs1(wp.z - 3.f) - 1.52f) >= max1(d, 0.f)) return d;
 		const vec3 q = vase_local(wp);
 		if (!beyond(q - V3(0.f, 1.2f, 0.f), max1(d, 0.f), 1.35f + 0.15f + 0.01f))
 			d = min1(d, vase(q));
@@ -321,7 +327,7 @@ struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
 	static constexpr int retire_after = 4; // its tiles are very uneven: configuration 4 1.60 (never) / 1.50 (4) / 1.55 (8) ms
-	static constexpr int waves_per_simd = 6; // configuration 4 with waves that retire: 1.47 (5) / 1.45 (6) / 1.48 (8) ms (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 7; // configuration 4, round 3, one session: 1.26 (5) / 1.22 (6) / 1.196 (7) / 1.193 (8) ms
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
