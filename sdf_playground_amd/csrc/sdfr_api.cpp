@@ -599,6 +599,7 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	rm.tile_row_mul = 1u;
 	rm.tile_row_add = 0u;
 	rm.retire_after = 0u;
+	rm.feedback_key = 0u;
 	const uint32_t frame_strips = (uint32_t)((height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS);
 	if (mode == RENDER_FULL)
 		rm.local_rows = height;

@@ -135,6 +135,10 @@ struct RowMap
 	uint32_t tile_row_mul, tile_row_add;
 	// persistent launches: a wave ends after this many tiles and a fresh one takes its place (0 = never); set by the launcher
 	uint32_t retire_after;
+	// row feedback (sdfr_pixel_kernel.h): what the launch's row order is valid for -- scene, frame size, which rows this launch
+	// renders (rank / world / strip split / private strips), tile shape -- folded into one word by the launcher (0 = no feedback);
+	// an order made by a launch with another key is not used
+	uint32_t feedback_key;
 };
 
 // local strip index of this launch -> strip index in the frame

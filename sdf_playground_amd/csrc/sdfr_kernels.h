@@ -51,7 +51,9 @@ hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_w
 // folds the per-block partial sums of a pixel-schedule launch into `totals` and puts the tile cursors back to zero
 // feedback_rows: tile rows of the launch if it was a persistent one whose rows should be re-ordered for the next frame (else 0)
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,
-	uint32_t feedback_rows, unsigned long long frame_pixels);
+	uint32_t feedback_rows, unsigned long long frame_pixels, uint32_t feedback_key);
+// RowMap::feedback_key of a launch: scene (index, or a hash of a run-time scene's name), frame width and what the row map selects
+uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm);
 int pixel_tile_cursor_words();
 // how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per
 // tile.  launch_mode: 0 = the scene's own default (PersistentTiles), 1 = one wave per tile, 2 = persistent;

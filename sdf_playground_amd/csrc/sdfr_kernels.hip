@@ -49,7 +49,7 @@ uint32_t launch_work_items(int width, const RowMap &rm)
 #define SDFR_REDUCE_THREADS 256
 #define SDFR_REDUCE_BLOCKS 64
 __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const RenderTotals *__restrict__ partials, uint32_t n, RenderTotals *totals,
-	uint32_t *tile_cursors, uint32_t feedback_rows, unsigned long long frame_pixels)
+	uint32_t *tile_cursors, uint32_t feedback_rows, unsigned long long frame_pixels, uint32_t feedback_key)
 {
 	// the pixel kernel before this one has drained its tile cursors: back to zero for the next launch
 	if (blockIdx.x == 0 && threadIdx.x < SDFR_TILE_CURSORS) tile_cursors[threadIdx.x * SDFR_TILE_CURSOR_STRIDE] = 0u;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(SDFR_REDUCE_THREADS) void k_reduce_totals(const Ren
 			const uint32_t i = k * SDFR_REDUCE_THREADS + threadIdx.x;
 			if (i < rows) row_order[bucket_base[my_bucket[k]] + my_place[k]] = i;
 		}
-		if (threadIdx.x == 0) *meta = rows; // 0: no order for the next launch
+		if (threadIdx.x == 0) *meta = rows ? feedback_key : 0u; // 0: no order for the next launch
 		return;
 	}
 	const uint32_t fold_blocks = gridDim.x > 1u ? gridDim.x - 1u : 1u;
@@ -175,8 +175,19 @@ uint32_t pixel_launch_blocks(const PixelLaunchMode &mode, uint32_t tiles, uint32
 	return blocks < tiles ? blocks : tiles;
 }
 
+uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm)
+{
+	// FNV-1a over what a row order depends on; never 0
+	uint32_t h = 2166136261u;
+	const uint32_t words[] = {scene_key, (uint32_t)width, (uint32_t)rm.local_rows, (uint32_t)rm.rank, (uint32_t)rm.world, (uint32_t)rm.tile_w_log2,
+		(uint32_t)rm.priv_count, (uint32_t)rm.priv_period, (uint32_t)rm.direct};
+	for (uint32_t w : words)
+		for (int b = 0; b < 4; ++b) h = (h ^ ((w >> (8 * b)) & 0xffu)) * 16777619u;
+	return h ? h : 1u;
+}
+
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,
-	uint32_t feedback_rows, unsigned long long frame_pixels)
+	uint32_t feedback_rows, unsigned long long frame_pixels, uint32_t feedback_key)
 {
 	static const bool feedback = [] { const char *e = getenv("SDFR_TILE_FEEDBACK"); return e ? atoi(e) != 0 : true; }(); // developer knob
 	uint32_t blocks = (n_blocks + SDFR_REDUCE_THREADS * 4 - 1) / (SDFR_REDUCE_THREADS * 4);
@@ -184,7 +195,7 @@ hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks,
 	if (blocks < 1) blocks = 1;
 	// one more block: it sorts the tile rows for the next frame while the others fold the counters
 	hipLaunchKernelGGL(k_reduce_totals, dim3(blocks + 1), dim3(SDFR_REDUCE_THREADS), 0, stream, partials, n_blocks, totals, tile_cursors,
-		feedback ? feedback_rows : 0u, frame_pixels);
+		feedback ? feedback_rows : 0u, frame_pixels, feedback_key);
 	return hipGetLastError();
 }
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_shade(FrameU U, RowMap rm, Wavef
 // =================================================================================================
 template <class Scene, bool DBG>
 static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-	const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
+	const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode, int scene_index)
 {
 	const uint32_t n_work = work_items(U, rm);
 	if ((size_t)n_work > ws.capacity) return hipErrorInvalidValue;
@@ -319,6 +319,7 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	const uint32_t blocks = pixel_launch_blocks(mode, tiles_blocks, (uint32_t)device_cu_count(device) * per_cu);
 	RowMap rows = rm;
 	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
+	rows.feedback_key = mode.persistent ? pixel_feedback_key((uint32_t)scene_index * 2u + (DBG ? 1u : 0u), U.width, rm) : 0u;
 	PixelKernelArgs args;
 	args.U = U;
 	args.rm = rows;
@@ -333,7 +334,8 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	args.tile_cursors = mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, args);
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
-	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? tiles_blocks / tiles_x : 0u, (unsigned long long)n_work);
+	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? tiles_blocks / tiles_x : 0u, (unsigned long long)n_work,
+		rows.feedback_key);
 }
 
 template <class Scene, bool DBG>
@@ -388,7 +390,7 @@ static hipError_t run_wavefront(const FrameU &U, const RowMap &rm, void *out, in
 template <class Scene, bool InGroup>
 struct GroupRunner
 {
-	static hipError_t pixel(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, int) { return hipErrorInvalidValue; }
+	static hipError_t pixel(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, int, int) { return hipErrorInvalidValue; }
 	static hipError_t wavefront(const FrameU &, const RowMap &, void *, int, uint32_t *, RenderTotals *, const WavefrontWorkspace &, hipStream_t, hipEvent_t *,
 		hipEvent_t *, int *)
 	{
@@ -399,10 +401,10 @@ template <class Scene>
 struct GroupRunner<Scene, true>
 {
 	static hipError_t pixel(const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
-		const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
+		const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode, int scene_index)
 	{
-		return frame_needs_debug(U) ? run_pixel<Scene, true>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode)
-									: run_pixel<Scene, false>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode);
+		return frame_needs_debug(U) ? run_pixel<Scene, true>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode, scene_index)
+									: run_pixel<Scene, false>(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode, scene_index);
 	}
 	static hipError_t wavefront(const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats, RenderTotals *totals,
 		const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events, int *n_rounds_out)
@@ -420,7 +422,7 @@ hipError_t SDFR_CAT(launch_pixel_group, SDFR_GROUP)(int scene, const FrameU &U, 
 {
 	switch (scene)
 	{
-#define SDFR_RUN(I, S) case I: return GroupRunner<S, (I) % SDFR_GROUPS == SDFR_GROUP>::pixel(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode);
+#define SDFR_RUN(I, S) case I: return GroupRunner<S, (I) % SDFR_GROUPS == SDFR_GROUP>::pixel(U, rows, out, format, pixel_stats, totals, ws, stream, launch_mode, I);
 		SDFR_FOR_EACH_SCENE(SDFR_RUN)
 #undef SDFR_RUN
 	default: return hipErrorInvalidValue;

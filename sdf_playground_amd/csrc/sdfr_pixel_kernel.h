@@ -332,7 +332,8 @@ struct LdsCachedRayStore
 // tile adds its march evaluations to its tile row's cost, the fold kernel that follows the launch sorts the rows by cost
 // (dearest first) into the order the NEXT frame's launch hands them out in, and clears the costs.  Frames of a sequence
 // resemble each other row by row (sky, horizon, floor) even when the camera turns.  State lives behind the tile cursors:
-// [META] rows the order was made for (anything else, e.g. 0 before the first frame: hand out top to bottom),
+// [META] key of the launch the order was made by (RowMap::feedback_key: scene, frame size, row selection, tile shape; anything
+// else, e.g. 0 before the first frame or after a frame with many rays per pixel: hand out top to bottom),
 // [COST ...] this frame's cost per row, [ORDER ...] the permutation.  Persistent launches of up to 512 tile rows.
 #define SDFR_ROW_FEEDBACK_MAX 512u
 #define SDFR_ROW_META (SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE)
@@ -445,8 +446,9 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	// row feedback (see SDFR_ROW_META): which rows come first, where this frame's costs go
 	const uint32_t fb_tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
 	const uint32_t fb_rows = (n_work >> 6) / fb_tiles_x;
-	const bool fb_on = tile_cursors != nullptr && fb_rows <= SDFR_ROW_FEEDBACK_MAX;
-	const uint32_t *row_order = fb_on && tile_cursors[SDFR_ROW_META] == fb_rows ? tile_cursors + SDFR_ROW_ORDER : nullptr;
+	const bool fb_on = tile_cursors != nullptr && fb_rows <= SDFR_ROW_FEEDBACK_MAX && rm.feedback_key != 0u;
+	const uint32_t *row_order = fb_on && tile_cursors[SDFR_ROW_META] == rm.feedback_key ? tile_cursors + SDFR_ROW_ORDER : nullptr;
+	const uint32_t fb_cost_cap = 0xffffffffu / (fb_tiles_x ? fb_tiles_x : 1u); // a row's cost is a 32-bit sum over its tiles: no wrap
 	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
 		age.tile_start();
@@ -485,7 +487,7 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 		if (fb_on && (threadIdx.x & 63u) == 0)
 		{
 			const uint32_t row = handed_out_row(rm, tile / fb_tiles_x, row_order);
-			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u);
+			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u < fb_cost_cap ? c + 64u : fb_cost_cap);
 			atomicAdd(tile_cursors + SDFR_ROW_RAYS + row, b);
 		}
 		tiles.tile_took(age.ticks_since_start());

@@ -10,7 +10,7 @@ C=${2:-3}
 OUT=gpurun_out/$R/cfg$C
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --config $C --steps 16 --warmup 2 --no-cpu-baseline --no-second-pass"
+CMD="bench.py --config $C --steps 16 --warmup 2 --no-cpu-baseline --no-second-pass --no-extra-passes"
 # .git does not travel to the GPU box: the caller stamps the tree (git rev-parse --short HEAD > .build_commit) before gpurun
 cp .build_commit $OUT/commit.txt 2>/dev/null || echo unknown > $OUT/commit.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $CMD > $OUT/stats.log 2>&1 || exit 1

@@ -83,7 +83,7 @@ if summary:
         commit = None
     out = {"round": rnd, "commit": commit,
            "workload": {"config": config, "key": cfg["key"], "width": cfg["width"], "height": cfg["height"], "schedule": "pixel"},
-           "command": "bench.py --config %s --steps 16 --warmup 2 --no-cpu-baseline --no-second-pass" % config,
+           "command": "bench.py --config %s --steps 16 --warmup 2 --no-cpu-baseline --no-second-pass --no-extra-passes" % config,
            "kernels": summary, "traffic": traffic,
            "hbm_bytes_per_launch": traffic[main[0]]["hbm_bytes_per_launch"] if main else None,
            "note": "PMC means per dispatch; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB (separate passes, gfx950 FETCH_SIZE correction)"}
