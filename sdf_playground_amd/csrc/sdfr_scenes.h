@@ -61,6 +61,7 @@ struct SceneCubeSea
 {
 	static const char *name() { return "cube_sea"; }
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
+	static constexpr int retire_after = 4; // at 4K, 256 steps: 2.98 (2) / 2.88 (4) / 2.98 (8) ms; configuration 2 (1080p) is indifferent, 0.75 ms from never to 8
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	static SDF_HD void prepare(FrameU &) {}
@@ -176,6 +177,7 @@ struct SceneLabyrinth
 	static const char *name() { return "labyrinth"; }
 	static constexpr int waves_per_simd = 7; // configuration 3, round 3 (argument block read on demand: 16 spilled registers instead of 30), one session: 1.247 (5) / 1.234 (6) / 1.226 (7) / 1.254 (8) ms; round 2 had 6 ahead of 7 by 3 % (profiles/r03_launch_experiments.txt)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
+	static constexpr int retire_after = 4; // configuration 3, two sessions: 1.252 (1) / 1.236 (2) / 1.224 (3) / 1.224 (4) / 1.233 (5) / 1.237 (8) / 1.243 (16) ms
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	enum { SU_FIRE_SCROLL = 0 };
@@ -326,7 +328,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
-	static constexpr int retire_after = 4; // its tiles are very uneven: configuration 4 1.60 (never) / 1.50 (4) / 1.55 (8) ms
+	static constexpr int retire_after = 2; // its tiles are very uneven: configuration 4, round 3: 1.203 (1) / 1.178 (2) / 1.199 (4) / 1.366 (6) / 1.38 (8) ms
 	static constexpr int waves_per_simd = 7; // configuration 4, round 3, one session: 1.26 (5) / 1.22 (6) / 1.196 (7) / 1.193 (8) ms
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
