@@ -82,6 +82,14 @@ public:
 		return refreshVariables();
 	}
 
+	// the same with the scene in the reference's own dialect: the text of a scenes/*.hlsl file as the reference compiles it
+	// (map / map_normal / map_light / map_background, the OBJECT and MATERIAL macros; sdfr_load_scene_hlsl)
+	bool initShaderHlsl(const std::string &name, const std::string &hlsl_text)
+	{
+		if (sdfr_load_scene_hlsl(handle, name.c_str(), hlsl_text.c_str()) != SDFR_OK) return false;
+		return refreshVariables();
+	}
+
 	// void setParameters(float stime)
 	void setParameters(float stime_) { stime = stime_; }
 

@@ -63,6 +63,8 @@ static void free_workspace(sdfr_renderer *r)
 static int ensure_workspace(sdfr_renderer *r, size_t pixels, bool wavefront)
 {
 	WavefrontWorkspace &w = r->ws;
+	// the pixel kernel indexes the pending-ray records with 32 bits (GlobalRayStore::record)
+	if (pixels * (size_t)SDFR_MAX_RAYS >= ((size_t)1 << 32)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "frame too large: more than 2^32 / 8 pixels per launch");
 	if (w.capacity < pixels || (wavefront && r->wavefront_capacity < pixels))
 	{
 		if (w.capacity < pixels) free_workspace(r);
@@ -119,8 +121,6 @@ int sdfr_create(int device_ordinal, sdfr_renderer **out)
 		if (v >= 3 && v <= 6) r->tile_w_log2 = v;
 	}
 	if (const char *t = getenv("SDFR_STEP_SHORTCUTS")) r->step_shortcuts = atoi(t) != 0; // default of sdfr_set_step_shortcuts
-	if (const char *t = getenv("SDFR_TILE_ORDER")) // developer knob: 0 top to bottom, 1 bottom to top, 2 interleaved rows
-		r->tile_order = atoi(t);
 	frame_defaults(r->U);
 	// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
 	host::Camera cam;
@@ -596,8 +596,7 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	rm.priv_count = mode == RENDER_FULL ? 0 : r->priv_count;
 	rm.priv_period = mode == RENDER_FULL ? 1 : r->priv_period;
 	rm.direct = mode == RENDER_PRIVATE ? 1 : 0;
-	rm.tile_row_mul = 1u;
-	rm.tile_row_add = 0u;
+	row_map_tiles(rm, width);
 	rm.retire_after = 0u;
 	rm.feedback_key = 0u;
 	const uint32_t frame_strips = (uint32_t)((height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS);
@@ -646,22 +645,6 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 		if (last_row_end > height && out_bytes) SDFR_HIP(hipMemsetAsync(d_out, 0, out_bytes, r->stream));
 	}
 
-	{
-		// the order the launch's waves take the tile rows in (developer knob SDFR_TILE_ORDER; RowMap)
-		const uint32_t th = 64u >> rm.tile_w_log2, tile_rows = ((uint32_t)rm.local_rows + th - 1u) / th;
-		if (r->tile_order == 1 && tile_rows > 1) // bottom to top
-		{
-			rm.tile_row_mul = tile_rows - 1u;
-			rm.tile_row_add = tile_rows - 1u;
-		}
-		else if (r->tile_order == 2 && tile_rows > 2) // interleaved: successive hand-outs are ~0.62 of the image height apart
-		{
-			uint32_t m = (uint32_t)(0.6180339887 * tile_rows);
-			auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
-			while (m > 1 && gcd(m, tile_rows) != 1) --m;
-			rm.tile_row_mul = m < 1 ? 1u : m;
-		}
-	}
 	const bool pixel_schedule = r->scene == SDFR_SCENE_COUNT || r->schedule == SDFR_SCHEDULE_PIXEL;
 	if (!pixel_schedule) SDFR_HIP(hipMemsetAsync(totals, 0, sizeof(RenderTotals), r->stream)); // the wavefront kernels add to it
 	hipError_t e;

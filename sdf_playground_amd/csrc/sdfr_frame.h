@@ -45,6 +45,9 @@ struct FrameU
 	// hit test, the MATERIAL / OBJECT_TRANSPARENT macros, sdSphereFast, the directional light's normalisation --, grad_eps
 	// 1e-4, reflect_eps 1e-3, refract_eps 1e-3, shadow_eps 3e-4) as run-time values (sdfr_limits); defaults = reference
 	float dist_eps, grad_eps, reflect_eps, refract_eps, shadow_eps;
+	// (float)width, (float)height (frame_derive): the vector unit is the only one that converts, and a kernel that made them
+	// itself would keep two vector registers on them for as long as a persistent wave lives
+	float widthf, heightf;
 };
 
 // One queued ray, 11 dwords.  last_transparent_pos of the reference's Ray struct
@@ -130,9 +133,9 @@ struct RowMap
 	int tile_w_log2; // a wave covers a (1 << tile_w_log2) x (64 >> tile_w_log2) pixel tile; 3..6
 	int priv_count, priv_period; // 0 <= priv_count < priv_period
 	int direct;                  // 1: this launch renders the private strips, pixel index = position in the full image
-	// order in which the launch's waves take the tile rows: tile row (ty * tile_row_mul + tile_row_add) % tile_rows
-	// is the ty-th to be handed out (an affine permutation: mul coprime to tile_rows; 1, 0 = top to bottom)
-	uint32_t tile_row_mul, tile_row_add;
+	// tiles per tile row of the launch, and floor(2^32 / tiles_x): a wave splits its tile index into row and column with
+	// scalar multiplies (tile_row_and_column) instead of the vector unit's integer division; set by the launcher (row_map_tiles)
+	uint32_t tiles_x, tiles_x_magic;
 	// persistent launches: a wave ends after this many tiles and a fresh one takes its place (0 = never); set by the launcher
 	uint32_t retire_after;
 	// row feedback (sdfr_pixel_kernel.h): what the launch's row order is valid for -- scene, frame size, which rows this launch
@@ -140,6 +143,25 @@ struct RowMap
 	// an order made by a launch with another key is not used
 	uint32_t feedback_key;
 };
+
+SDF_HD void row_map_tiles(RowMap &rm, int width)
+{
+	rm.tiles_x = ((uint32_t)width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	rm.tiles_x_magic = rm.tiles_x > 1u ? (uint32_t)(0x100000000ull / rm.tiles_x) : 0xffffffffu;
+}
+// tile / tiles_x and tile % tiles_x: with m = floor(2^32 / d) the estimate mulhi(n, m) is the quotient or one below it
+SDF_HD void tile_row_and_column(const RowMap &rm, uint32_t tile, uint32_t &row, uint32_t &column)
+{
+	uint32_t q = (uint32_t)(((unsigned long long)tile * rm.tiles_x_magic) >> 32);
+	uint32_t r = tile - q * rm.tiles_x;
+	if (r >= rm.tiles_x)
+	{
+		q += 1u;
+		r -= rm.tiles_x;
+	}
+	row = q;
+	column = r;
+}
 
 // local strip index of this launch -> strip index in the frame
 SDF_HD uint32_t strip_local_to_global(const RowMap &rm, uint32_t ls)

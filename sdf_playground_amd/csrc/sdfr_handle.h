@@ -21,7 +21,6 @@ struct sdfr_renderer
 	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
 	bool profiling = false;
 	int tile_w_log2 = 3;
-	int tile_order = 0; // SDFR_TILE_ORDER
 	int launch_mode = 0; // sdfr_set_launch_mode
 	int priv_count = 0, priv_period = 1; // sdfr_set_strip_split
 	sdfr::FrameU U;

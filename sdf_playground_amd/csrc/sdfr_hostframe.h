@@ -31,8 +31,10 @@ inline void frame_derive(FrameU &U, int scene_index)
 	U.debug_plane_on = any3(n) ? 1 : 0;
 	U.debug_normal = U.debug_plane_on ? normalize(n) : V3s(0.f);
 	U.show_on = (U.show_objects != 0.f) ? 1 : 0;
-	U.ddx = 2.f / (float)U.width;
-	U.ddy = -2.f / (float)U.height;
+	U.widthf = (float)U.width;
+	U.heightf = (float)U.height;
+	U.ddx = 2.f / U.widthf;
+	U.ddy = -2.f / U.heightf;
 	vec2 sc = sincos1(-U.stime * 0.025f);
 	U.sky_s = sc.x;
 	U.sky_c = sc.y;

@@ -22,8 +22,8 @@ struct PixelRay
 };
 SDF_HD PixelRay pixel_ray(const FrameU &U, int px, int py)
 {
-	float sx = ((float)px + 0.5f) / (float)U.width * 2.f - 1.f;
-	float sy = 1.f - ((float)py + 0.5f) / (float)U.height * 2.f;
+	float sx = ((float)px + 0.5f) / U.widthf * 2.f - 1.f;
+	float sy = 1.f - ((float)py + 0.5f) / U.heightf * 2.f;
 	vec3 d = U.front + sx * U.right + sy * U.top;
 	float invlen = rcp1(length(d));
 	PixelRay r;

@@ -45,6 +45,17 @@ struct PixelWavesPerSimd<Scene, typename VoidOf<decltype(Scene::waves_per_simd)>
 #endif
 #define SDFR_PIXEL_KERNEL_ATTRS(Scene) __launch_bounds__(SDFR_PIXEL_BLOCK) __attribute__((amdgpu_waves_per_eu(PixelWavesPerSimd<Scene>::value)))
 
+// This lane's index in its wave, made where it is needed (three instructions).  A block of the pixel kernel is one wave, so
+// this is threadIdx.x -- which arrives in v0 and cannot be re-made: kept for the whole life of a persistent wave it is a vector
+// register at the march loop or a scratch slot that every tile reloads.  The opaque zero keeps the compiler from hoisting the
+// computation back out of the tile loop.
+__device__ __forceinline__ uint32_t lane_now()
+{
+	uint32_t zero = 0;
+	asm volatile("" : "+s"(zero));
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+}
+
 // ---- pixel mapping ------------------------------------------------------------------------------
 // Work item w -> pixel: consecutive groups of 64 items form an 8x8 tile so that a wave sees
 // neighbouring pixels (coherent materials, similar step counts).  The tile shape is a launch
@@ -54,25 +65,16 @@ struct PixelCoord
 	int px, py;   // in the full frame
 	uint32_t pid; // index in this launch's (compact) image
 };
-// which tile row the ty-th row to be handed out is: the launch's affine order (RowMap), or -- `order` -- last frame's
+// which tile row the ty-th row to be handed out is: top to bottom, or -- `order` -- last frame's
 // rows sorted by what they cost (row feedback, below)
-__device__ __forceinline__ uint32_t handed_out_row(const RowMap &rm, uint32_t ty, const uint32_t *order)
-{
-	if (rm.tile_row_mul != 1u || rm.tile_row_add != 0u)
-	{
-		const uint32_t th_log2 = 6u - (uint32_t)rm.tile_w_log2;
-		const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
-		return (ty * rm.tile_row_mul + rm.tile_row_add) % tiles_y;
-	}
-	return order ? order[ty] : ty;
-}
-__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc, const uint32_t *order = nullptr)
+__device__ __forceinline__ uint32_t handed_out_row(uint32_t ty, const uint32_t *order) { return order ? order[ty] : ty; }
+// lane `lane` of the wave that renders tile `tile` (wave-uniform: the split into row and column is scalar work)
+__device__ __forceinline__ bool tile_to_pixel(const FrameU &U, const RowMap &rm, uint32_t tile, uint32_t lane, PixelCoord &pc, const uint32_t *order = nullptr)
 {
 	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
-	const uint32_t tiles_x = ((uint32_t)U.width + (1u << tw_log2) - 1u) >> tw_log2;
-	const uint32_t tile = w >> 6, lane = w & 63u;
-	const uint32_t tx = tile % tiles_x;
-	const uint32_t ty = handed_out_row(rm, tile / tiles_x, order);
+	uint32_t row, tx;
+	tile_row_and_column(rm, tile, row, tx);
+	const uint32_t ty = handed_out_row(row, order);
 	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
 	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
@@ -83,6 +85,7 @@ __device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm,
 	pc.pid = (uint32_t)(rm.direct ? py : lrow) * (uint32_t)U.width + (uint32_t)px;
 	return true;
 }
+__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc) { return tile_to_pixel(U, rm, w >> 6, w & 63u, pc); }
 __device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, uint32_t pid, int &px, int &py)
 {
 	const uint32_t lrow = pid / (uint32_t)U.width;
@@ -207,7 +210,9 @@ struct GlobalRayStore
 	float *queue;
 	size_t cap;
 	uint32_t pid;
-	__device__ __forceinline__ float4 *record(int slot) const { return reinterpret_cast<float4 *>(queue) + ((size_t)slot * cap + pid) * 3; }
+	// (a 32-bit record index -- the workspace holds fewer than 2^32 records, sdfr_api.cpp -- so that no zero-extended pixel index
+	// has to live in a register pair)
+	__device__ __forceinline__ float4 *record(int slot) const { return reinterpret_cast<float4 *>(queue) + (size_t)((uint32_t)slot * (uint32_t)cap + pid) * 3; }
 	__device__ __forceinline__ void put(int slot, const RayRec &r)
 	{
 		float4 *rec = record(slot);
@@ -291,6 +296,10 @@ struct LdsCachedRayStore
 		p[0 * SDFR_PIXEL_BLOCK] = pr.right_ray.x; p[1 * SDFR_PIXEL_BLOCK] = pr.right_ray.y; p[2 * SDFR_PIXEL_BLOCK] = pr.right_ray.z;
 		p[3 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.x; p[4 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.y; p[5 * SDFR_PIXEL_BLOCK] = pr.bottom_ray.z;
 	}
+	// (the tone-map flag in LDS as well -- one more field -- measured slower: labyrinth 4K 1.199 -> 1.240 ms, profiles/r03_launch_experiments.txt)
+	float hdr_reg;
+	__device__ __forceinline__ void keep_hdr(float h) { hdr_reg = h; }
+	__device__ __forceinline__ float hdr_kept() const { return hdr_reg; }
 	__device__ __forceinline__ PixelRay pixel_ray_kept() const
 	{
 		const lds_float *p = lds + SDFR_LDS_RAY_FIELDS * SDFR_PIXEL_BLOCK;
@@ -384,7 +393,7 @@ struct TileQueue
 			const uint32_t in_shard = tiles_of(shard);
 			const uint32_t want = batch;
 			uint32_t k = 0;
-			if ((threadIdx.x & 63u) == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, want) : 0u;
+			if (lane_now() == 0) k = in_shard ? atomicAdd(cursors + shard * SDFR_TILE_CURSOR_STRIDE, want) : 0u;
 			k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
 			if (k < in_shard)
 			{
@@ -435,7 +444,7 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 #endif
 	const uint32_t waves_per_block = SDFR_PIXEL_BLOCK / 64u;
 	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u, 0u, 0u, 1u, 0u};
-	tiles.start(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
+	tiles.start(blockIdx.x);
 	TileTimer age = {0ull};
 #ifdef SDFR_PHASE_CLOCKS
 	PixelCounters clk = {};
@@ -444,10 +453,13 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	// shuffles per tile) and kept wave-uniform, so that no lane carries them through the bounce loop
 	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0, tiles_done = 0;
 	// row feedback (see SDFR_ROW_META): which rows come first, where this frame's costs go
-	const uint32_t fb_tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
-	const uint32_t fb_rows = (n_work >> 6) / fb_tiles_x;
+	const uint32_t fb_tiles_x = rm.tiles_x;
+	uint32_t fb_rows, fb_rest;
+	tile_row_and_column(rm, n_work >> 6, fb_rows, fb_rest);
 	const bool fb_on = tile_cursors != nullptr && fb_rows <= SDFR_ROW_FEEDBACK_MAX && rm.feedback_key != 0u;
-	const uint32_t *row_order = fb_on && tile_cursors[SDFR_ROW_META] == rm.feedback_key ? tile_cursors + SDFR_ROW_ORDER : nullptr;
+	// (one word for the whole wave: read as a scalar, or the pointer below becomes a pair of vector registers)
+	const uint32_t fb_meta = fb_on ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_cursors[SDFR_ROW_META]) : 0u;
+	const uint32_t *row_order = fb_on && fb_meta == rm.feedback_key ? tile_cursors + SDFR_ROW_ORDER : nullptr;
 	const uint32_t fb_cost_cap = 0xffffffffu / (fb_tiles_x ? fb_tiles_x : 1u); // a row's cost is a 32-bit sum over its tiles: no wrap
 	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
@@ -455,10 +467,11 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 		PixelCounters pcnt = {};
 		uint32_t pix = 0;
 		PixelCoord pc;
-		if (work_to_pixel(U, rm, tile * 64u + (threadIdx.x & 63u), pc, row_order))
+		const uint32_t lane = lane_now();
+		if (tile_to_pixel(U, rm, tile, lane, pc, row_order))
 		{
 			GlobalRayStore backing = {ray_queue, cap, pc.pid};
-			LdsCachedRayStore store(backing, &lds_rays[0][threadIdx.x]);
+			LdsCachedRayStore store(backing, &lds_rays[0][lane]);
 			vec4 v = render_pixel<Scene, DBG, LdsCachedRayStore>(U, pc.px, pc.py, pcnt, store);
 			store_pixel(out, format, pc.pid, v, (uint32_t)rm.local_rows * (uint32_t)U.width);
 			if (pixel_stats)
@@ -473,20 +486,28 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 #endif
 		}
 		uint32_t a = pix, b = pcnt.rays, c = pcnt.march_evals, d = pcnt.hits;
-		for (int off = 32; off > 0; off >>= 1)
 		{
-			a += __shfl_xor(a, off);
-			b += __shfl_xor(b, off);
-			c += __shfl_xor(c, off);
-			d += __shfl_xor(d, off);
+			// (__shfl_xor makes the lane index by itself, and the compiler keeps that one for the life of the wave)
+			const uint32_t me = lane_now();
+#pragma unroll
+			for (uint32_t off = 32; off > 0; off >>= 1)
+			{
+				const int peer = (int)((me ^ off) << 2);
+				a += (uint32_t)__builtin_amdgcn_ds_bpermute(peer, (int)a);
+				b += (uint32_t)__builtin_amdgcn_ds_bpermute(peer, (int)b);
+				c += (uint32_t)__builtin_amdgcn_ds_bpermute(peer, (int)c);
+				d += (uint32_t)__builtin_amdgcn_ds_bpermute(peer, (int)d);
+			}
 		}
 		w_pixels += (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
 		w_rays += (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
 		w_evals += (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-		if (fb_on && (threadIdx.x & 63u) == 0)
+		if (fb_on && lane_now() == 0)
 		{
-			const uint32_t row = handed_out_row(rm, tile / fb_tiles_x, row_order);
+			uint32_t tile_row, tile_column;
+			tile_row_and_column(rm, tile, tile_row, tile_column);
+			const uint32_t row = handed_out_row(tile_row, row_order);
 			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u < fb_cost_cap ? c + 64u : fb_cost_cap);
 			atomicAdd(tile_cursors + SDFR_ROW_RAYS + row, b);
 		}
@@ -527,9 +548,12 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 		return;
 	}
 #endif
-	// the wave's sums are uniform: lane 0 of each wave speaks for it
-	const bool speaks = (threadIdx.x & 63u) == 0;
-	block_store_totals(partials, speaks ? w_pixels : 0u, speaks ? w_rays : 0u, speaks ? w_evals : 0u, speaks ? w_hits : 0u);
+	// the wave's sums are uniform and the block is this wave: lanes 0-3 write one counter each
+	{
+		const uint32_t l = lane_now();
+		const uint32_t v = l == 0 ? w_pixels : l == 1 ? w_rays : l == 2 ? w_evals : w_hits;
+		if (l < 4) reinterpret_cast<unsigned long long *>(&partials[blockIdx.x])[l] = (unsigned long long)v;
+	}
 }
 
 } // namespace sdfr

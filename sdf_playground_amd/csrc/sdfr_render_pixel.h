@@ -24,7 +24,8 @@ struct LocalRayStore
 // travels to HBM and back.
 //
 // A store also keeps the pixel's ray footprint (PixelRay) between the prologue and the hit
-// shading that needs it for the checker filter: keep_pixel_ray / pixel_ray_kept.
+// shading that needs it for the checker filter: keep_pixel_ray / pixel_ray_kept; and the pixel's
+// tone-map flag, which only hit shading touches: keep_hdr / hdr_kept.
 template <class Backing>
 struct CachedRayStore
 {
@@ -32,9 +33,12 @@ struct CachedRayStore
 	RayRec cached;
 	int cached_slot;
 	PixelRay kept;
+	float hdr;
 	SDF_HD explicit CachedRayStore(Backing &b) : backing(b), cached_slot(-1) {}
 	SDF_HD void keep_pixel_ray(const PixelRay &pr) { kept = pr; }
 	SDF_HD PixelRay pixel_ray_kept() const { return kept; }
+	SDF_HD void keep_hdr(float h) { hdr = h; }
+	SDF_HD float hdr_kept() const { return hdr; }
 	SDF_HD void ray_marched(const RayRec &r, uint32_t iter, int status) { backing.ray_marched(r, iter, status); }
 	SDF_HD void put(int i, const RayRec &r)
 	{
@@ -138,7 +142,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 	uint64_t depths = SDFR_QUEUE_EMPTY;
 	int count = 0; // rays waiting in the store
 
-	float hdr = -1.f;
+	store.keep_hdr(-1.f); // hdr_output "not set" (pshader_sdf.hlsl:284)
 	vec3 acc = V3s(0.f);
 	for (int bounce = 0; bounce < U.bounce_count; ++bounce)
 	{
@@ -227,7 +231,9 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			SDFR_CLK_ADD(clk_grad, c1, c2);
 
 			Spawner<Store> q(store, depths, count, U.ray_count);
+			float hdr = store.hdr_kept();
 			out = shade_hit<Scene, DBG, Store>(U, F, ray, store.pixel_ray_kept(), hit, max_range, hdr, q);
+			store.keep_hdr(hdr);
 			depths = q.depths;
 			count = q.count;
 #ifdef SDFR_PHASE_CLOCKS
@@ -249,7 +255,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 	}
 	SDFR_CLK(c_end);
 	SDFR_CLK_ADD(clk_total, c_begin, c_end);
-	return V4(acc.x, acc.y, acc.z, abs1(hdr));
+	return V4(acc.x, acc.y, acc.z, abs1(store.hdr_kept()));
 }
 
 } // namespace sdfr

@@ -30,6 +30,7 @@ class FrameU(ctypes.Structure):
         ("step_shortcuts", ctypes.c_int),
         ("dist_eps", ctypes.c_float), ("grad_eps", ctypes.c_float), ("reflect_eps", ctypes.c_float), ("refract_eps", ctypes.c_float),
         ("shadow_eps", ctypes.c_float),
+        ("widthf", ctypes.c_float), ("heightf", ctypes.c_float),
     ]
 
 
