@@ -23,8 +23,11 @@ def main():
     idx = int(re.search(r"X\((\d+), %s\)" % scene, text).group(1))
     groups = int(re.search(r"#define SDFR_GROUPS (\d+)", text).group(1))
     out = "/tmp/isa_%s.s" % scene
+    sys.path.insert(0, ROOT)
+    from sdf_playground_amd.buildlib import GROUP_FLAGS  # the group's own allocator options, unless the caller passes some
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-x", "hip", "-Wno-unused-result",
-           "-Wno-unknown-pragmas", "-I" + CSRC, "-DSDFR_GROUP=%d" % (idx % groups), "--cuda-device-only", "-S", os.path.join(CSRC, "sdfr_kernels_group.hip"), "-o", out] + sys.argv[2:]
+           "-Wno-unknown-pragmas", "-I" + CSRC, "-DSDFR_GROUP=%d" % (idx % groups), "--cuda-device-only", "-S", os.path.join(CSRC, "sdfr_kernels_group.hip"), "-o", out] + \
+          (sys.argv[2:] or GROUP_FLAGS.get(idx % groups, []))
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4sdfr7k_pixelINS_\d+%sELb0.*:" % scene, l))
@@ -43,23 +46,34 @@ def main():
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             loops.add((labels[m.group(1)], i))
 
+    def one_bank(l):
+        """a three-source instruction (v_fma_f32; v_fmac_f32, whose destination is the addend) with all three vector sources in one
+        register bank (number mod 4) issues at half rate: tools/ubench/bank_ubench.hip, profiles/r03_bank_ubench.txt"""
+        m = re.match(r"(v_\w+)\s+(.*)", l.split(";")[0])
+        if not m:
+            return False
+        ops = [o.strip() for o in m.group(2).split(",")]
+        srcs = ops if m.group(1).startswith(("v_fmac", "v_mac")) else ops[1:]
+        regs = [int(x.group(1)) for x in (re.match(r"^[-|]*v(\d+)\|?$", o) for o in srcs) if x]
+        return len(regs) >= 3 and len(set(r % 4 for r in regs)) == 1
+
     def stats(a, b):
         ins = [l.strip() for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
         valu = [l for l in ins if l.startswith("v_")]
         sgpr_operand = sum(1 for l in valu if not l.startswith(HALF + TRANS) and re.search(r"[, ]s\d+|[, ]s\[", l.split(";")[0]))
         return dict(n=len(ins), valu=len(valu), half=sum(1 for l in valu if l.startswith(HALF)), trans=sum(1 for l in valu if l.startswith(TRANS)),
-                    sgpr_op=sgpr_operand, salu=sum(1 for l in ins if l.startswith("s_")), scratch=sum(1 for l in ins if l.startswith("scratch_")),
+                    sgpr_op=sgpr_operand, one_bank=sum(1 for l in valu if one_bank(l)), fma=sum(1 for l in valu if l.startswith(("v_fma_f32", "v_fmac_f32"))), salu=sum(1 for l in ins if l.startswith("s_")), scratch=sum(1 for l in ins if l.startswith("scratch_")),
                     lds=sum(1 for l in ins if l.startswith("ds_")), vmem=sum(1 for l in ins if l.startswith(("global_", "buffer_", "flat_"))))
 
     print("%s: kernel %d lines" % (scene, len(body)))
-    print("  lines          insts  valu  (half-rate  trans  full+sgpr-operand)  salu scratch lds vmem")
+    print("  lines          insts  valu  (half-rate  trans  full+sgpr-operand)  salu scratch lds vmem   fma/fmac: three sources in one bank")
     for a, b in sorted(loops, key=lambda x: x[1] - x[0]):
         s = stats(a, b)
         if s["valu"] < 40:
             continue
-        print("  %5d-%5d  %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d" % (a, b, s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"]))
+        print("  %5d-%5d  %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d   %4d: %d" % (a, b, s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"], s["fma"], s["one_bank"]))
     s = stats(0, len(body) - 1)
-    print("  whole kernel   %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d" % (s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"]))
+    print("  whole kernel   %6d %5d  (%5d %6d %6d)  %13d %5d %4d %4d   %4d: %d" % (s["n"], s["valu"], s["half"], s["trans"], s["sgpr_op"], s["salu"], s["scratch"], s["lds"], s["vmem"], s["fma"], s["one_bank"]))
 
 
 main()
