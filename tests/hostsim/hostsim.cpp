@@ -59,6 +59,16 @@ extern "C" int hostsim_render(const char *scene, FrameU *frame, float *out_rgba,
 	return 0;
 }
 
+// RowMap's scalar split of a tile index into row and column (sdfr_frame.h): returns row * 2^32 + column for a frame `width` wide
+extern "C" unsigned long long hostsim_tile_split(int width, int tile_w_log2, unsigned tile)
+{
+	RowMap rm = {};
+	rm.tile_w_log2 = tile_w_log2;
+	row_map_tiles(rm, width);
+	uint32_t row, column;
+	tile_row_and_column(rm, tile, row, column);
+	return ((unsigned long long)row << 32) | column;
+}
 extern "C" int hostsim_scene_count() { return SDFR_PUBLIC_SCENE_COUNT; }
 extern "C" const char *hostsim_scene_name(int i) { return scene_name(i); }
 extern "C" int hostsim_frame_size() { return (int)sizeof(FrameU); }
