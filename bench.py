@@ -267,9 +267,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-steps", action="store_true",
                     help="march every step of every ray (sdfr_set_step_shortcuts off): the step counters then equal the reference's; the pixels are the same either way")
-    ap.add_argument("--min-seconds", type=float, default=0.0,
+    ap.add_argument("--min-seconds", type=float, default=None,
                     help="N = 1: after the K timed steps keep looping the sweep for at least this long and report that steady-state figure beside "
-                         "the K-step one (`steady`): 32 steps are 40 ms, shorter than a clock ramp")
+                         "the K-step one (`steady`): 32 steps are 40 ms, shorter than a clock ramp (default: 2 s; 0 with --no-extra-passes)")
     ap.add_argument("--no-extra-passes", action="store_true",
                     help="N = 1: skip the informational passes after the timed region (every step marched; the reference's own iter_count 100)")
     ap.add_argument("--no-second-pass", action="store_true",
@@ -952,7 +952,8 @@ def run(a, world):
                                                note="the reference's own limits (iter_count 100, max_cost 7, one light table): pure reference semantics, SURVEY.md 8(d)")
             except Exception as e:
                 out["extra_passes_error"] = repr(e)
-        if not distributed and a.min_seconds > 0:
+        min_seconds = a.min_seconds if a.min_seconds is not None else (0.0 if a.no_extra_passes else 2.0)
+        if not distributed and min_seconds > 0:
             # a steady-state figure: the same steps, looped for at least --min-seconds (the K-step region is tens of milliseconds)
             torch.cuda.synchronize()
             ts = time.perf_counter()
@@ -962,7 +963,7 @@ def run(a, world):
                     step(n_steady + s)
                 n_steady += SWEEP
                 torch.cuda.synchronize()
-                if time.perf_counter() - ts >= a.min_seconds:
+                if time.perf_counter() - ts >= min_seconds:
                     break
             secs = time.perf_counter() - ts
             rays_steady = sum(rays_per_frame[s % len(rays_per_frame)] for s in range(n_steady))
