@@ -829,6 +829,9 @@ def run(a, world):
                 "parallelism": "strips%d" % world if distributed else "single",
                 "rays_per_pixel": total_rays / a.steps / (W * H),
                 "step_shortcuts": not a.exact_steps,
+                # persistent launches hand out the tile rows of a frame dearest first by what the PREVIOUS frame of the same scene, size and row
+                # selection cost (sdfr_pixel_kernel.h, row feedback): the timed steps follow the warm-up steps of the same sweep
+                "tile_row_order": "from the previous frame's row costs (warm-up frames included); pixels do not depend on it",
             },
         }
         if distributed:
