@@ -168,6 +168,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
 	(void)sdfr_peer_region_close(r);
 	if (r->peer_status) (void)hipHostFree(r->peer_status);
+	if (r->d_peer_gave_up) (void)hipFree(r->d_peer_gave_up);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);

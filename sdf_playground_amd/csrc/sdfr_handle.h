@@ -73,6 +73,7 @@ struct sdfr_renderer
 	bool peer_owner = false;
 	uint32_t peer_frame = 0;        // frames gathered through this region so far
 	uint32_t *peer_status = nullptr, *d_peer_status = nullptr; // this rank's "a wait gave up" word: mapped host memory, host / device view
+	uint32_t *d_peer_gave_up = nullptr;                        // the same word in device memory: what the kernels that follow a wait look at
 };
 
 static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)

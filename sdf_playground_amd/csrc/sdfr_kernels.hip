@@ -258,7 +258,7 @@ __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, 
 	uint32_t *image, int format, int priv_count, int priv_period, const uint32_t *skip_if_set)
 {
 	// the peer-copy gather: a wait before this launch gave up, the slots are not this frame's (sdfr_peer.hip)
-	if (skip_if_set && __hip_atomic_load(skip_if_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	if (skip_if_set && *skip_if_set != 0u) return; // device memory, written by a kernel before this one on the stream
 	const uint32_t px = blockIdx.x * SDFR_BLOCK + threadIdx.x, py = blockIdx.y;
 	if (px >= (uint32_t)width) return;
 	uint32_t strip = py >> 3; // becomes the index among the shared strips

@@ -10,8 +10,10 @@
 //   rank 0   a one-wave kernel waits until every arrived[p] has reached the frame number, k_assemble scatters
 //            the slots into the image, a one-thread kernel stores the frame number into `released`
 // Waits are bounded (2 s of the 100-MHz clock): a rank that never arrives makes the wait give up instead of hanging
-// the GPU.  A wait that gave up says so in a status word of this rank's own (host memory the GPU writes through a
-// mapping), and what follows it on the stream looks at that word first: the copy into rank 0's slot and rank 0's
+// the GPU.  A wait that gave up says so in a status word of this rank's own -- twice: in host memory that the GPU writes
+// through a mapping (the host reads it without a synchronisation) and in device memory, which is what the kernels that
+// follow on the stream look at first (every thread of the assembly reads it: over PCIe that was 17 ms per 4K frame) --
+// and those are then skipped: the copy into rank 0's slot and rank 0's
 // assembly are SKIPPED (no torn frame: a peer must not write a slot rank 0 may still be reading), the next
 // sdfr_render_gather_peer refuses with SDFR_ERR_COMM, sdfr_peer_region_status reports it, and only a new region
 // (create / open) clears it.  The flag words other devices write while a kernel polls them are fine-grained memory.
@@ -39,17 +41,18 @@ static_assert(sizeof(Descriptor) <= SDFR_PEER_REGION_BYTES, "SDFR_PEER_REGION_BY
 
 // lanes 0 .. n-1 each wait for flags[first + lane] >= value; every wave of the grid reaches the end.  A wait that gives
 // up (or finds that an earlier one has) leaves the frame number in *status: what follows on the stream is skipped.
-__global__ void k_peer_wait(uint32_t *flags, int first, int n, uint32_t value, uint32_t *status, uint32_t frame)
+__global__ void k_peer_wait(uint32_t *flags, int first, int n, uint32_t value, uint32_t *status, uint32_t *gave_up, uint32_t frame)
 {
 	const int lane = (int)threadIdx.x;
 	if (lane >= n) return;
-	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	if (__hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 	while (__hip_atomic_load(flags + first + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value)
 	{
 		if (__builtin_amdgcn_s_memrealtime() - t0 > PEER_WAIT_TICKS)
 		{
 			__hip_atomic_store(status, frame ? frame : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(gave_up, frame ? frame : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return;
 		}
 		__builtin_amdgcn_s_sleep(32);
@@ -59,7 +62,7 @@ __global__ void k_peer_wait(uint32_t *flags, int first, int n, uint32_t value, u
 // a peer's strips into its slot of rank 0's buffer, over the link -- unless a wait gave up (see the head of the file)
 __global__ __launch_bounds__(256) void k_peer_copy(uint32_t *dst, const uint32_t *src, size_t words, const uint32_t *status)
 {
-	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 	const size_t stride = (size_t)gridDim.x * blockDim.x, quads = words / 4;
 	const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
 	uint4 *d4 = reinterpret_cast<uint4 *>(dst);
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void k_peer_copy(uint32_t *dst, const uint32_t
 }
 __global__ void k_peer_signal_unless(uint32_t *flag, uint32_t value, const uint32_t *status)
 {
-	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+	if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 	__threadfence_system();
 	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -91,7 +94,9 @@ int status_word(sdfr_renderer *r)
 		SDFR_HIP(hipHostMalloc((void **)&r->peer_status, 64, hipHostMallocMapped));
 		SDFR_HIP(hipHostGetDevicePointer((void **)&r->d_peer_status, r->peer_status, 0));
 	}
+	if (!r->d_peer_gave_up) SDFR_HIP(hipMalloc((void **)&r->d_peer_gave_up, 64));
 	*r->peer_status = 0u; // a new region starts clean
+	SDFR_HIP(hipMemset(r->d_peer_gave_up, 0, 64));
 	return SDFR_OK;
 }
 
@@ -283,23 +288,23 @@ int sdfr_render_gather_peer(sdfr_renderer *r, int rank, int world, int width, in
 		if (nb && world > 1)
 		{
 			// the region is free once rank 0 has assembled the frame before out of it
-			hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_RELEASED, 1, frame - 1u, r->d_peer_status, frame);
+			hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_RELEASED, 1, frame - 1u, r->d_peer_status, r->d_peer_gave_up, frame);
 			// (a kernel, not hipMemcpyAsync: a copy engine cannot be told to skip a frame whose wait gave up)
 			hipLaunchKernelGGL(k_peer_copy, dim3(256), dim3(256), 0, r->comm_stream, reinterpret_cast<uint32_t *>((char *)r->peer_buffer + (size_t)rank * nb),
-				reinterpret_cast<const uint32_t *>(r->d_wire), nb / 4, r->d_peer_status);
-			hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_ARRIVED + rank, frame, r->d_peer_status);
+				reinterpret_cast<const uint32_t *>(r->d_wire), nb / 4, r->d_peer_gave_up);
+			hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_ARRIVED + rank, frame, r->d_peer_gave_up);
 		}
 	}
 	else
 	{
 		if (nb)
 		{
-			if (world > 1) hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_ARRIVED + 1, world - 1, frame, r->d_peer_status, frame);
+			if (world > 1) hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, r->comm_stream, flags, (int)FLAG_ARRIVED + 1, world - 1, frame, r->d_peer_status, r->d_peer_gave_up, frame);
 			hipError_t e = launch_assemble_strips(width, height, world, r->peer_buffer, root_image, wire_format, r->priv_count, r->priv_period, r->comm_stream,
-				r->d_peer_status);
+				r->d_peer_gave_up);
 			if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
 		}
-		if (world > 1) hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_RELEASED, frame, r->d_peer_status);
+		if (world > 1) hipLaunchKernelGGL(k_peer_signal_unless, dim3(1), dim3(1), 0, r->comm_stream, flags + FLAG_RELEASED, frame, r->d_peer_gave_up);
 		if (r->priv_count > 0)
 		{
 			r->caller_times = true;
