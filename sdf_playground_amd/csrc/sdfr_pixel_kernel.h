@@ -440,7 +440,7 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	__shared__ float lds_rays[SDFR_LDS_RAY_FIELDS + SDFR_LDS_PIXEL_RAY_FIELDS][SDFR_PIXEL_BLOCK];
 #ifdef SDFR_WAVE_TRACE
 	const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-	uint32_t trace_tiles = 0;
+	uint32_t trace_tiles = 0, trace_ticks = 0; // tiles rendered; 10-ns ticks from taking a tile to having rendered it, summed
 #endif
 	const uint32_t waves_per_block = SDFR_PIXEL_BLOCK / 64u;
 	TileQueue tiles = {tile_cursors, n_work >> 6, gridDim.x * waves_per_block, 0u, 0u, 0u, 0u, 1u, 0u};
@@ -461,9 +461,17 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	const uint32_t fb_meta = fb_on ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_cursors[SDFR_ROW_META]) : 0u;
 	const uint32_t *row_order = fb_on && fb_meta == rm.feedback_key ? tile_cursors + SDFR_ROW_ORDER : nullptr;
 	const uint32_t fb_cost_cap = 0xffffffffu / (fb_tiles_x ? fb_tiles_x : 1u); // a row's cost is a 32-bit sum over its tiles: no wrap
+#ifdef SDFR_WAVE_TRACE
+	unsigned long long trace_mark = __builtin_amdgcn_s_memrealtime();
+	uint32_t trace_first_claim = 0, trace_claims = 0;
+#endif
 	for (uint32_t tile = tiles.next(); tile != SDFR_NO_TILE; tile = tiles.next())
 	{
 		age.tile_start();
+#ifdef SDFR_WAVE_TRACE
+		// from the end of the tile before (the kernel's first instruction, for the first tile) to having the next one
+		if (trace_claims++ == 0) trace_first_claim = (uint32_t)(age.t0 - trace_mark);
+#endif
 		PixelCounters pcnt = {};
 		uint32_t pix = 0;
 		PixelCoord pc;
@@ -511,6 +519,10 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u < fb_cost_cap ? c + 64u : fb_cost_cap);
 			atomicAdd(tile_cursors + SDFR_ROW_RAYS + row, b);
 		}
+#ifdef SDFR_WAVE_TRACE
+		trace_ticks += age.ticks_since_start();
+		trace_mark = __builtin_amdgcn_s_memrealtime();
+#endif
 		tiles.tile_took(age.ticks_since_start());
 		// make room for a younger wave (pixel_launch_blocks, sdfr_kernels.h) -- but never with claimed tiles in hand
 		if (rm.retire_after && ++tiles_done >= rm.retire_after && !tiles.holds_claimed_tiles()) break;
@@ -520,16 +532,17 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	}
 #ifdef SDFR_WAVE_TRACE
 	// developer build (tools/wave_trace.py): the per-block record carries when and where the wave ran
-	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, tiles | march evaluations << 32
+	// instead of its counters: {start, end} in 10-ns ticks, HW_ID | XCC_ID << 32, tiles (8 bits) | ticks until it had its first tile (24 bits) << 8 | ticks spent rendering << 32
+	// (a wave's life minus those ticks is what it waited for tiles -- the cursor's round trip, the row-order look-up -- and its start-up)
 	{
-		const uint32_t ev = w_evals;
+		const uint32_t ev = trace_ticks;
 		if (threadIdx.x == 0)
 		{
 			unsigned long long *rec = reinterpret_cast<unsigned long long *>(&partials[blockIdx.x]);
 			rec[0] = trace_t0;
 			rec[1] = __builtin_amdgcn_s_memrealtime();
 			rec[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-			rec[3] = (unsigned long long)trace_tiles | ((unsigned long long)ev << 32);
+			rec[3] = (unsigned long long)(trace_tiles & 0xffu) | ((unsigned long long)(trace_first_claim & 0xffffffu) << 8) | ((unsigned long long)ev << 32);
 		}
 		return;
 	}

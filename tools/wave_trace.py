@@ -75,7 +75,8 @@ def main():
         np.add.at(d, np.minimum(t1.astype(np.int64) + 1, n), -1)
         occ = np.cumsum(d)[:n]
         peak = occ.max()
-        tiles_done = (rec[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+        tiles_done = (rec[:, 3] & np.uint64(0xff)).astype(np.int64)
+        first_claim_us = ((rec[:, 3] >> np.uint64(8)) & np.uint64(0xffffff)).astype(np.int64) * 0.01
         print("config %s frame %d: event %.3f ms; first start -> last end %.1f us; %d waves, %d tiles (per wave min %d mean %.1f max %d); peak resident %d; mean resident %.0f (%.2f of peak)" % (
             a.config, k, ms, T, nwaves, tiles_done.sum(), tiles_done.min(), tiles_done.mean(), tiles_done.max(), peak, occ.mean(), occ.mean() / peak))
         for frac in (0.9, 0.5, 0.25):
@@ -86,13 +87,19 @@ def main():
         print("   ramp-up to 90 %%: %.1f us; last time at 90 %%: %.1f us (tail %.1f us)" % (hi[0], hi[-1], T - hi[-1]))
         q = np.percentile(life, [5, 25, 50, 75, 95, 99, 100])
         print("   wave lifetime us: p5 %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f p99 %.1f max %.1f; sum of lifetimes / (T x peak) = %.3f" % (*q, life.sum() / (T * peak)))
+        tile_us = (rec[:, 3] >> np.uint64(32)).astype(np.int64) * 0.01
+        print("   time between taking a tile and having rendered it, summed / wave lifetimes summed: %.4f (the rest: waiting for a tile, start-up, wind-down); per tile not rendering: %.2f us" % (
+            tile_us.sum() / life.sum(), (life.sum() - tile_us.sum()) / max(1, tiles_done.sum())))
+        had = tiles_done >= 0
+        print("   from a wave's first instruction to having its first tile, us: p5 %.1f p50 %.1f p95 %.1f mean %.1f (x %d waves = %.1f %% of the lifetimes)" % (
+            *np.percentile(first_claim_us[had], [5, 50, 95]), first_claim_us[had].mean(), nwaves, 100.0 * first_claim_us.sum() / life.sum()))
         ends = [t1[xcc == x].max() for x in range(8) if (xcc == x).any()]
         cnt = [int((xcc == x).sum()) for x in range(8)]
         print("   per-XCD last wave end (us): %s; waves per XCD: %s" % (" ".join("%.0f" % e for e in ends), cnt))
         # launch order vs start time: how far ahead of the finishing front does the dispatcher run
         print("   wave end time quantiles (us): %s" % " ".join("%.0f" % q for q in np.percentile(t1, [0, 1, 5, 25, 50, 75, 95, 99, 100])))
         late = np.argsort(t1)[-8:]
-        print("   the 8 last waves: " + "; ".join("[%.0f..%.0f] tiles %d ev %d" % (t0[b], t1[b], int(tiles_done[b]), int(rec[b, 3] >> np.uint64(32))) for b in late))
+        print("   the 8 last waves: " + "; ".join("[%.0f..%.0f] tiles %d rendering %.0f us" % (t0[b], t1[b], int(tiles_done[b]), 0.01 * int(rec[b, 3] >> np.uint64(32))) for b in late))
         np.savez_compressed(os.path.join(a.out, "cfg%s_frame%d.npz" % (a.config, k)), rec=rec, ms=ms)
     r.close()
 
