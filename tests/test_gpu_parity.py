@@ -324,7 +324,11 @@ def test_kernels_reproduce_256x256_digests(renderer, case):
 
     renderer.initShader(case["scene"])
     renderer.setParameters(case["stime"])
-    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0)
+    # every limit, also the extensions and the epsilons: the handle is shared by the module's tests, and whatever ran before this one
+    # (which depends on the -k selection) must not leak into the digests
+    renderer.setLimits(iter_count=100, bounce_count=16, ray_count=8, light_count=8, range=100.0, max_cost_default=7, extension_lights=0,
+                       extension_marble_reflection=0.0, dist_eps=0.0001, grad_eps=0.0001, reflect_eps=0.001, refract_eps=0.001, shadow_eps=0.0003)
+    renderer.resetVariables()
     renderer.setLimits(**case["limits"])
     cam = sp.Camera()          # Application.cpp:214-224
     cam.SetAspect(1.0)
