@@ -26,13 +26,37 @@ OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_hlsl.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_peer.hip", "sdfr_post.hip"]
 GROUP_SOURCE = "sdfr_kernels_group.hip"
 ARCH = "gfx950"
-# Per scene group: options that only change the register ASSIGNMENT.  A three-source instruction (v_fma_f32, v_fmac_f32) whose
-# sources all lie in one VGPR bank (register number mod 4) issues at half rate on gfx950 (tools/ubench/bank_ubench.hip,
-# profiles/r03_bank_ubench.txt), the allocator does not know, and how many of a march loop's fma land that way is luck:
-# tools/isa_loops.py counts them.  Group 3 (fractal, coordinate_material, terrain): 15 of the fractal march loop's 104 fma
-# with the default order, 4 with local live ranges assigned shortest first; measured -2.0 / -1.1 / -1.9 % at 4K, BASELINE
-# configuration 4 -1.2 % (profiles/r03_launch_experiments.txt).  The other groups measured equal or worse with it.
-GROUP_FLAGS = {3: ["-mllvm", "-greedy-reverse-local-assignment"]}
+# Per scene: options that change the register ASSIGNMENT or the instruction ORDER of its kernels, never the arithmetic.  A three-source
+# instruction (v_fma_f32, v_fmac_f32) whose sources all lie in one VGPR bank (register number mod 4) issues at half rate on gfx950
+# (tools/ubench/bank_ubench.hip, profiles/r03_bank_ubench.txt), the allocator does not know, and how many of a march loop's fma land
+# that way is luck: tools/isa_loops.py counts them, and a scene whose default draw is a bad one gets another (each scene is a compile
+# unit of its own).  Chosen by that count, kept where the GPU confirmed it (profiles/r03_launch_experiments.txt):
+#   fractal 15 -> 4 of its march loop's 104 fma, coordinate_material, terrain (-2.0 / -1.1 / -1.9 % at 4K), tiling (-4 %): local live ranges
+#   assigned shortest first; cube_sea 4 -> 2 of 33 (BASELINE configuration 2 -2.1 %), shell (-2 %): scheduler strategy max-memory-clause;
+#   lense 12 -> 0 of 79 (configuration 5 -0.9 %): top-down pre-RA scheduling (which costs distortion 12 %, hence per scene).
+_REV = ["-mllvm", "-greedy-reverse-local-assignment"]
+_MAXMEM = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
+_TOPDOWN = ["-mllvm", "-misched-prera-direction=topdown"]
+SCENE_FLAGS = {"SceneFractal": _REV, "SceneCoordinateMaterial": _REV, "SceneTerrain": _REV, "SceneTiling": _REV,
+               "SceneCubeSea": _MAXMEM, "SceneShell": _MAXMEM, "SceneLense": _TOPDOWN}
+
+
+def scene_registry():
+    """[(index, struct name)] of the scenes compiled ahead of time (csrc/sdfr_perpixel.h)."""
+    text = open(os.path.join(CSRC, "sdfr_perpixel.h")).read()
+    return [(int(i), n) for i, n in re.findall(r"X\((\d+), (Scene\w+)\)", text)]
+
+
+def group_flags(g):
+    """Options of compile unit g: those of the scenes in it (one scene per unit: SDFR_GROUPS >= scene count)."""
+    groups = scene_groups()
+    flags = []
+    for i, name in scene_registry():
+        if i % groups == g:
+            flags += [f for f in SCENE_FLAGS.get(name, []) if f not in flags or f == "-mllvm"]
+    return flags
+
+
 FLAGS = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-x", "hip", "-Wno-unused-result",
          "-Wno-unknown-pragmas", "-I" + CSRC]
 
@@ -62,7 +86,7 @@ def build(force=False, verbose=False, extra=(), out=None, jobs=None):
     objdir = os.path.join(OBJDIR, hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else "default")
     os.makedirs(objdir, exist_ok=True)
     units = [(s, [], os.path.join(objdir, s + ".o")) for s in SOURCES]
-    units += [(GROUP_SOURCE, ["-DSDFR_GROUP=%d" % g] + GROUP_FLAGS.get(g, []), os.path.join(objdir, "%s.%d.o" % (GROUP_SOURCE, g))) for g in range(scene_groups())]
+    units += [(GROUP_SOURCE, ["-DSDFR_GROUP=%d" % g] + group_flags(g), os.path.join(objdir, "%s.%d.o" % (GROUP_SOURCE, g))) for g in range(scene_groups())]
     newest_dep = max(os.path.getmtime(d) for d in _deps())
 
     def compile_unit(u):

@@ -24,10 +24,10 @@ def main():
     groups = int(re.search(r"#define SDFR_GROUPS (\d+)", text).group(1))
     out = "/tmp/isa_%s.s" % scene
     sys.path.insert(0, ROOT)
-    from sdf_playground_amd.buildlib import GROUP_FLAGS  # the group's own allocator options, unless the caller passes some
+    from sdf_playground_amd.buildlib import group_flags  # the scene's own code-generation options, unless the caller passes some
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-x", "hip", "-Wno-unused-result",
            "-Wno-unknown-pragmas", "-I" + CSRC, "-DSDFR_GROUP=%d" % (idx % groups), "--cuda-device-only", "-S", os.path.join(CSRC, "sdfr_kernels_group.hip"), "-o", out] + \
-          (sys.argv[2:] or GROUP_FLAGS.get(idx % groups, []))
+          (sys.argv[2:] or group_flags(idx % groups))
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4sdfr7k_pixelINS_\d+%sELb0.*:" % scene, l))
