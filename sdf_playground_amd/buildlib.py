@@ -1,8 +1,9 @@
 """Builds libsdfr.so (C ABI + gfx950 kernels) in-tree with hipcc.
 
 Every source is compiled to an object of its own, in parallel; the per-scene kernels
-(csrc/sdfr_kernels_group.hip) are compiled once per scene group (-DSDFR_GROUP=g, SDFR_GROUPS of them),
-which is what makes the build take ~15 s on 8 cores instead of a minute.
+(csrc/sdfr_kernels_group.hip) are compiled once per scene (-DSDFR_GROUP=<scene index>, SDFR_GROUPS units), so that
+the build takes ~20 s on 8 cores instead of a minute and a scene can have code-generation options of its own
+(SCENE_FLAGS below).
 
 Flags that matter for correctness:
   -ffp-contract=off   only the explicit fma() calls fuse (arithmetic contract)

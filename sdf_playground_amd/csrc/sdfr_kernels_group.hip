@@ -2,7 +2,8 @@
 // sdfr_kernels.hip for the two schedules), instantiated for ONE group of scenes.  The build compiles
 // this file SDFR_GROUPS times with -DSDFR_GROUP=0.. (sdf_playground_amd/buildlib.py), in parallel:
 // 23 scenes x 2 debug variants x 3 kernels in one translation unit took a minute to compile, and
-// nothing in one scene's kernels depends on another's.  Scene i belongs to group i % SDFR_GROUPS.
+// nothing in one scene's kernels depends on another's.  Scene i belongs to group i % SDFR_GROUPS; with SDFR_GROUPS >= the number
+// of scenes (sdfr_perpixel.h) every scene is a unit of its own and can be built with its own options (buildlib.SCENE_FLAGS).
 #include "sdfr_kernels.h"
 #include "sdfr_perpixel.h"
 #include "sdfr_pixel_kernel.h"
