@@ -598,6 +598,7 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	rm.priv_period = mode == RENDER_FULL ? 1 : r->priv_period;
 	rm.direct = mode == RENDER_PRIVATE ? 1 : 0;
 	row_map_tiles(rm, width);
+	rm.unit_log2 = rm.units_x = rm.units_x_magic = rm.units = 0u; // the launcher of a persistent launch decides (row_map_units)
 	rm.retire_after = 0u;
 	rm.feedback_key = 0u;
 	const uint32_t frame_strips = (uint32_t)((height + SDFR_STRIP_ROWS - 1) / SDFR_STRIP_ROWS);
@@ -651,7 +652,7 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	hipError_t e;
 	if (rm.local_rows == 0) return SDFR_OK; // e.g. every strip of a small frame is private
 	{
-		size_t need = (size_t)launch_work_items(width, rm);
+		size_t need = (size_t)launch_capacity_items(width, rm);
 		if (need < local_pixels) need = local_pixels; // private strips index the workspace by image position
 		rc = ensure_workspace(r, need, !pixel_schedule);
 	}

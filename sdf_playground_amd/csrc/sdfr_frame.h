@@ -136,6 +136,10 @@ struct RowMap
 	// tiles per tile row of the launch, and floor(2^32 / tiles_x): a wave splits its tile index into row and column with
 	// scalar multiplies (tile_row_and_column) instead of the vector unit's integer division; set by the launcher (row_map_tiles)
 	uint32_t tiles_x, tiles_x_magic;
+	// Hand-out units of a persistent full-frame launch (row_map_units): the frame's tiles in squares of (1 << unit_log2)^2 tiles, handed out
+	// unit by unit (dearest first by last frame's cost: the feedback of sdfr_pixel_kernel.h is kept per UNIT, not per tile row -- an object in
+	// the middle of the picture is dear in the middle of many rows).  unit_log2 = 0: no units, tile rows as they are.
+	uint32_t unit_log2, units_x, units_x_magic, units;
 	// persistent launches: a wave ends after this many tiles and a fresh one takes its place (0 = never); set by the launcher
 	uint32_t retire_after;
 	// row feedback (sdfr_pixel_kernel.h): what the launch's row order is valid for -- scene, frame size, which rows this launch
@@ -148,6 +152,40 @@ SDF_HD void row_map_tiles(RowMap &rm, int width)
 {
 	rm.tiles_x = ((uint32_t)width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
 	rm.tiles_x_magic = rm.tiles_x > 1u ? (uint32_t)(0x100000000ull / rm.tiles_x) : 0xffffffffu;
+}
+// squares of tiles such that the frame has at most `max_units` of them; not for strip launches (their rows are not the frame's)
+SDF_HD void row_map_units(RowMap &rm, uint32_t max_units)
+{
+	rm.unit_log2 = 0u;
+	rm.units_x = rm.units_x_magic = rm.units = 0u;
+	if (rm.world != 1 || rm.priv_count != 0 || rm.direct != 0) return;
+	const uint32_t th_log2 = 6u - (uint32_t)rm.tile_w_log2;
+	const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
+	for (uint32_t l = 1u; l <= 8u; ++l)
+	{
+		const uint32_t ux = (rm.tiles_x + (1u << l) - 1u) >> l, uy = (tiles_y + (1u << l) - 1u) >> l;
+		if (ux * uy <= max_units)
+		{
+			rm.unit_log2 = l;
+			rm.units_x = ux;
+			rm.units_x_magic = ux > 1u ? (uint32_t)(0x100000000ull / ux) : 0xffffffffu;
+			rm.units = ux * uy;
+			return;
+		}
+	}
+}
+// n / d and n % d with m = floor(2^32 / d): the estimate mulhi(n, m) is the quotient or one below it
+SDF_HD void split_by_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t &quotient, uint32_t &rest)
+{
+	uint32_t q = (uint32_t)(((unsigned long long)n * magic) >> 32);
+	uint32_t r = n - q * d;
+	if (r >= d)
+	{
+		q += 1u;
+		r -= d;
+	}
+	quotient = q;
+	rest = r;
 }
 // tile / tiles_x and tile % tiles_x: with m = floor(2^32 / d) the estimate mulhi(n, m) is the quotient or one below it
 SDF_HD void tile_row_and_column(const RowMap &rm, uint32_t tile, uint32_t &row, uint32_t &column)

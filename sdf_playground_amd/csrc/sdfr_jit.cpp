@@ -204,15 +204,17 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	(void)hipGetDevice(&device);
 	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, false); // a run-time scene: one wave per tile unless asked otherwise
 	if (mode.blocks_per_cu > 0 && mode.blocks_per_cu < per_cu) per_cu = mode.blocks_per_cu;
-	const uint32_t blocks = pixel_launch_blocks(mode, (n_work + bt - 1u) / bt, (uint32_t)(device_cu_count(device) * per_cu));
 	PixelKernelArgs pk;
 	pk.U = U;
 	pk.rm = rm;
+	const uint32_t hand_out_items = n_work; // (tile rows: squares of tiles -- RowMap::unit_log2 -- are a built-in scene's own choice)
+	if ((size_t)hand_out_items > ws.capacity) return hipErrorInvalidValue;
+	const uint32_t blocks = pixel_launch_blocks(mode, (hand_out_items + bt - 1u) / bt, (uint32_t)(device_cu_count(device) * per_cu));
 	pk.rm.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
 	uint32_t name_hash = 2166136261u; // a run-time scene is known by its name
 	for (char ch : js.name) name_hash = (name_hash ^ (unsigned char)ch) * 16777619u;
-	pk.rm.feedback_key = mode.persistent ? pixel_feedback_key(0x80000000u | name_hash | (frame_needs_debug(U) ? 1u : 0u), U.width, rm) : 0u;
-	pk.n_work = n_work;
+	pk.rm.feedback_key = mode.persistent ? pixel_feedback_key(0x80000000u | name_hash | (frame_needs_debug(U) ? 1u : 0u), U.width, pk.rm) : 0u;
+	pk.n_work = hand_out_items;
 	pk.format = format;
 	pk.out = out;
 	pk.pixel_stats = pixel_stats;
@@ -226,8 +228,8 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
-	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? ((n_work + bt - 1u) / bt) / tiles_x : 0u, (unsigned long long)n_work,
-		pk.rm.feedback_key);
+	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors, !mode.persistent ? 0u : pk.rm.unit_log2 ? pk.rm.units : ((n_work + bt - 1u) / bt) / tiles_x,
+		(unsigned long long)n_work, pk.rm.feedback_key);
 }
 
 } // namespace sdfr

@@ -76,5 +76,6 @@ int pixel_block_threads(); // block size of the pixel kernels (partials are size
 int device_cu_count(int device);
 // work items (padded to whole tiles) of a launch: lists and per-pixel state are sized by this
 uint32_t launch_work_items(int width, const RowMap &rm);
+uint32_t launch_capacity_items(int width, const RowMap &rm); // >= launch_work_items: what the workspace of a launch is sized for
 
 } // namespace sdfr

@@ -39,6 +39,17 @@ uint32_t launch_work_items(int width, const RowMap &rm)
 	const uint32_t tiles_y = ((uint32_t)rm.local_rows + (1u << th_log2) - 1u) >> th_log2;
 	return tiles_x * tiles_y * 64u;
 }
+// what a handle's per-launch scratch is sized for: the work items, or -- a persistent launch hands a full frame out in squares of tiles that
+// cover it with a margin (row_map_units), and launches at most one block per tile handed out -- the items of those squares
+uint32_t launch_capacity_items(int width, const RowMap &rm)
+{
+	const uint32_t items = launch_work_items(width, rm);
+	RowMap units = rm;
+	row_map_tiles(units, width);
+	row_map_units(units, SDFR_ROW_FEEDBACK_MAX);
+	const uint32_t padded = units.unit_log2 ? (units.units << (2u * units.unit_log2)) * 64u : 0u;
+	return padded > items ? padded : items;
+}
 
 // =================================================================================================
 // kernels that do not depend on the scene (the per-scene ones: sdfr_kernels_group.hip)
@@ -186,7 +197,7 @@ uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm)
 	// FNV-1a over what a row order depends on; never 0
 	uint32_t h = 2166136261u;
 	const uint32_t words[] = {scene_key, (uint32_t)width, (uint32_t)rm.local_rows, (uint32_t)rm.rank, (uint32_t)rm.world, (uint32_t)rm.tile_w_log2,
-		(uint32_t)rm.priv_count, (uint32_t)rm.priv_period, (uint32_t)rm.direct};
+		(uint32_t)rm.priv_count, (uint32_t)rm.priv_period, (uint32_t)rm.direct, rm.unit_log2};
 	for (uint32_t w : words)
 		for (int b = 0; b < 4; ++b) h = (h ^ ((w >> (8 * b)) & 0xffu)) * 16777619u;
 	return h ? h : 1u;

@@ -4,6 +4,8 @@
 // 23 scenes x 2 debug variants x 3 kernels in one translation unit took a minute to compile, and
 // nothing in one scene's kernels depends on another's.  Scene i belongs to group i % SDFR_GROUPS; with SDFR_GROUPS >= the number
 // of scenes (sdfr_perpixel.h) every scene is a unit of its own and can be built with its own options (buildlib.SCENE_FLAGS).
+#include <cstdlib>
+
 #include "sdfr_kernels.h"
 #include "sdfr_perpixel.h"
 #include "sdfr_pixel_kernel.h"
@@ -317,14 +319,23 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	const PixelLaunchMode mode = pixel_launch_mode(launch_mode, PersistentTiles<Scene>::value, RetireAfter<Scene>::value);
 	uint32_t per_cu = (uint32_t)blocks_per_cu;
 	if (mode.blocks_per_cu > 0 && (uint32_t)mode.blocks_per_cu < per_cu) per_cu = (uint32_t)mode.blocks_per_cu;
-	const uint32_t blocks = pixel_launch_blocks(mode, tiles_blocks, (uint32_t)device_cu_count(device) * per_cu);
 	RowMap rows = rm;
+	uint32_t hand_out_items = n_work;
+	static const bool squares_off = [] { const char *e = getenv("SDFR_PIXEL_SQUARE_UNITS"); return e && atoi(e) == 0; }(); // developer knob: tile rows for every scene
+	if (mode.persistent && SquareUnits<Scene>::value && !squares_off)
+	{
+		// full frames are handed out in squares of tiles, dearest square first (RowMap::unit_log2); the squares cover the frame with a margin
+		row_map_units(rows, SDFR_ROW_FEEDBACK_MAX);
+		if (rows.unit_log2) hand_out_items = (rows.units << (2u * rows.unit_log2)) * 64u;
+	}
+	if ((size_t)hand_out_items > ws.capacity) return hipErrorInvalidValue; // one counter record per block, at most one block per tile handed out
+	const uint32_t blocks = pixel_launch_blocks(mode, (hand_out_items + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK, (uint32_t)device_cu_count(device) * per_cu);
 	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
-	rows.feedback_key = mode.persistent ? pixel_feedback_key((uint32_t)scene_index * 2u + (DBG ? 1u : 0u), U.width, rm) : 0u;
+	rows.feedback_key = mode.persistent ? pixel_feedback_key((uint32_t)scene_index * 2u + (DBG ? 1u : 0u), U.width, rows) : 0u;
 	PixelKernelArgs args;
 	args.U = U;
 	args.rm = rows;
-	args.n_work = n_work;
+	args.n_work = hand_out_items;
 	args.format = format;
 	args.out = out;
 	args.pixel_stats = pixel_stats;
@@ -335,8 +346,8 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	args.tile_cursors = mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, args);
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
-	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, mode.persistent ? tiles_blocks / tiles_x : 0u, (unsigned long long)n_work,
-		rows.feedback_key);
+	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, !mode.persistent ? 0u : rows.unit_log2 ? rows.units : tiles_blocks / tiles_x,
+		(unsigned long long)n_work, rows.feedback_key);
 }
 
 template <class Scene, bool DBG>

@@ -69,12 +69,31 @@ struct PixelCoord
 // rows sorted by what they cost (row feedback, below)
 __device__ __forceinline__ uint32_t handed_out_row(uint32_t ty, const uint32_t *order) { return order ? order[ty] : ty; }
 // lane `lane` of the wave that renders tile `tile` (wave-uniform: the split into row and column is scalar work)
+// the unit (square of tiles, RowMap::unit_log2) the `slot`-th unit to be handed out is
+__device__ __forceinline__ uint32_t handed_out_unit(uint32_t slot, const uint32_t *order) { return order ? order[slot] : slot; }
+// UNITS: the kernel of a scene that may be handed out in squares (SquareUnits, sdfr_render_pixel.h); the others do not carry the code
+template <bool UNITS = false>
 __device__ __forceinline__ bool tile_to_pixel(const FrameU &U, const RowMap &rm, uint32_t tile, uint32_t lane, PixelCoord &pc, const uint32_t *order = nullptr)
 {
 	const uint32_t tw_log2 = (uint32_t)rm.tile_w_log2, th_log2 = 6u - tw_log2;
-	uint32_t row, tx;
-	tile_row_and_column(rm, tile, row, tx);
-	const uint32_t ty = handed_out_row(row, order);
+	uint32_t tx, ty;
+	if (UNITS && rm.unit_log2)
+	{
+		// hand-out index -> unit slot and tile within the unit (raster order inside the square); tiles of an edge unit may lie outside the frame
+		const uint32_t ul = rm.unit_log2, within = tile & ((1u << (2u * ul)) - 1u);
+		const uint32_t unit = handed_out_unit(tile >> (2u * ul), order);
+		uint32_t uy, ux;
+		split_by_magic(unit, rm.units_x, rm.units_x_magic, uy, ux);
+		tx = (ux << ul) + (within & ((1u << ul) - 1u));
+		ty = (uy << ul) + (within >> ul);
+		if (tx >= rm.tiles_x) return false;
+	}
+	else
+	{
+		uint32_t row;
+		tile_row_and_column(rm, tile, row, tx);
+		ty = handed_out_row(row, order);
+	}
 	const int px = (int)((tx << tw_log2) + (lane & ((1u << tw_log2) - 1u)));
 	const int lrow = (int)((ty << th_log2) + (lane >> tw_log2));
 	if (px >= U.width || lrow >= rm.local_rows) return false;
@@ -85,7 +104,7 @@ __device__ __forceinline__ bool tile_to_pixel(const FrameU &U, const RowMap &rm,
 	pc.pid = (uint32_t)(rm.direct ? py : lrow) * (uint32_t)U.width + (uint32_t)px;
 	return true;
 }
-__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc) { return tile_to_pixel(U, rm, w >> 6, w & 63u, pc); }
+__device__ __forceinline__ bool work_to_pixel(const FrameU &U, const RowMap &rm, uint32_t w, PixelCoord &pc) { return tile_to_pixel<false>(U, rm, w >> 6, w & 63u, pc); }
 __device__ __forceinline__ void pid_to_pixel(const FrameU &U, const RowMap &rm, uint32_t pid, int &px, int &py)
 {
 	const uint32_t lrow = pid / (uint32_t)U.width;
@@ -344,7 +363,9 @@ struct LdsCachedRayStore
 // [META] key of the launch the order was made by (RowMap::feedback_key: scene, frame size, row selection, tile shape; anything
 // else, e.g. 0 before the first frame or after a frame with many rays per pixel: hand out top to bottom),
 // [COST ...] this frame's cost per row, [ORDER ...] the permutation.  Persistent launches of up to 512 tile rows.
+#ifndef SDFR_ROW_FEEDBACK_MAX
 #define SDFR_ROW_FEEDBACK_MAX 512u
+#endif
 #define SDFR_ROW_META (SDFR_TILE_CURSORS * SDFR_TILE_CURSOR_STRIDE)
 #define SDFR_ROW_COST (SDFR_ROW_META + 32u)
 #define SDFR_ROW_ORDER (SDFR_ROW_COST + SDFR_ROW_FEEDBACK_MAX)
@@ -453,9 +474,13 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 	// shuffles per tile) and kept wave-uniform, so that no lane carries them through the bounce loop
 	uint32_t w_pixels = 0, w_rays = 0, w_evals = 0, w_hits = 0, tiles_done = 0;
 	// row feedback (see SDFR_ROW_META): which rows come first, where this frame's costs go
-	const uint32_t fb_tiles_x = rm.tiles_x;
+	constexpr bool UNITS = SquareUnits<Scene>::value;
+	const uint32_t fb_tiles_x = UNITS && rm.unit_log2 ? 1u << (2u * rm.unit_log2) : rm.tiles_x; // tiles per feedback unit (square, or tile row)
 	uint32_t fb_rows, fb_rest;
-	tile_row_and_column(rm, n_work >> 6, fb_rows, fb_rest);
+	if (UNITS && rm.unit_log2)
+		fb_rows = rm.units;
+	else
+		tile_row_and_column(rm, n_work >> 6, fb_rows, fb_rest);
 	const bool fb_on = tile_cursors != nullptr && fb_rows <= SDFR_ROW_FEEDBACK_MAX && rm.feedback_key != 0u;
 	// (one word for the whole wave: read as a scalar, or the pointer below becomes a pair of vector registers)
 	const uint32_t fb_meta = fb_on ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_cursors[SDFR_ROW_META]) : 0u;
@@ -476,7 +501,7 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 		uint32_t pix = 0;
 		PixelCoord pc;
 		const uint32_t lane = lane_now();
-		if (tile_to_pixel(U, rm, tile, lane, pc, row_order))
+		if (tile_to_pixel<UNITS>(U, rm, tile, lane, pc, row_order))
 		{
 			GlobalRayStore backing = {ray_queue, cap, pc.pid};
 			LdsCachedRayStore store(backing, &lds_rays[0][lane]);
@@ -513,9 +538,15 @@ __device__ __forceinline__ void pixel_kernel(const PixelKernelArgs &args_by_valu
 		w_hits += (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
 		if (fb_on && lane_now() == 0)
 		{
-			uint32_t tile_row, tile_column;
-			tile_row_and_column(rm, tile, tile_row, tile_column);
-			const uint32_t row = handed_out_row(tile_row, row_order);
+			uint32_t row;
+			if (UNITS && rm.unit_log2)
+				row = handed_out_unit(tile >> (2u * rm.unit_log2), row_order);
+			else
+			{
+				uint32_t tile_row, tile_column;
+				tile_row_and_column(rm, tile, tile_row, tile_column);
+				row = handed_out_row(tile_row, row_order);
+			}
 			atomicAdd(tile_cursors + SDFR_ROW_COST + row, c + 64u < fb_cost_cap ? c + 64u : fb_cost_cap);
 			atomicAdd(tile_cursors + SDFR_ROW_RAYS + row, b);
 		}

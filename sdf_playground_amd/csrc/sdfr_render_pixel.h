@@ -85,6 +85,15 @@ struct PersistentTiles<Scene, typename VoidOf<decltype(Scene::persistent_tiles)>
 	static constexpr bool value = Scene::persistent_tiles;
 };
 
+// A scene may say `static constexpr bool square_units = true;`: its persistent full-frame launches hand the tiles out in squares (RowMap::
+// unit_log2) instead of tile rows, dearest square first by the last frame's cost -- for a scene that is an object in the middle of the picture,
+// whose dear tiles sit in the middle of many rows (fractal: BASELINE configuration 4 1.174 -> 1.062 ms; the labyrinth +1.6 %, cube_sea +2.8 %,
+// lense with 8 lights +17 %: their cost runs along rows, and squares in image order scatter what rows keep together).
+template <class Scene, class = void>
+struct SquareUnits { static constexpr bool value = false; };
+template <class Scene>
+struct SquareUnits<Scene, typename VoidOf<decltype(Scene::square_units)>::type> { static constexpr bool value = Scene::square_units; };
+
 // tiles a wave of the scene's persistent launch renders before it makes room for a younger one (pixel_launch_blocks,
 // sdfr_kernels.h); a scene may say `static constexpr int retire_after = n;` (0 = never)
 template <class Scene, class = void>

@@ -328,6 +328,7 @@ struct SceneLabyrinth
 struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
+	static constexpr bool square_units = true; // an object in the middle of the picture: its dear tiles are handed out first (sdfr_render_pixel.h)
 	static constexpr int retire_after = 2; // its tiles are very uneven: configuration 4, round 3: 1.203 (1) / 1.178 (2) / 1.199 (4) / 1.366 (6) / 1.38 (8) ms
 	static constexpr int waves_per_simd = 7; // configuration 4, round 3, one session: 1.26 (5) / 1.22 (6) / 1.196 (7) / 1.193 (8) ms
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
@@ -616,6 +617,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr bool square_units = true; // an object in the middle of the picture (sdfr_render_pixel.h): configuration 5g -1.9 %, at 4K with the start-up camera -5.7 %
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int retire_after = 2; // configuration 5g, one session (profiles/r03_launch_experiments.txt): 1.74 (8) / 1.68 (2) / 1.71 (1) ms
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)

@@ -1,7 +1,7 @@
 """GPU tier: the persistent launch's tile hand-out (TileQueue, sdfr_pixel_kernel.h) -- from the second frame of a size
-on, rows are handed out dearest first from the front of the order to the fast SIMD slots and from the back to the slow
-ones, with an end game for the fast ones.  Whatever the order: every pixel is rendered (a sentinel survives nowhere) and
-equals the one-wave-per-tile launch bit for bit, counters included."""
+on, tile rows (or, for a scene that says so, squares of tiles) are handed out dearest first by the frame before.  Whatever
+the order: every pixel is rendered (a sentinel survives nowhere) and equals the one-wave-per-tile launch bit for bit,
+counters included."""
 import numpy as np
 import pytest
 
@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("scene,size", [("labyrinth", (1283, 721)), ("cube_sea", (640, 360)), ("fast_sphere", (1920, 1080)), ("fractal", (333, 1203)),
-                                        ("light_shadows", (64, 8)), ("gems", (8, 3000))])
+                                        ("light_shadows", (64, 8)), ("gems", (8, 3000)),
+                                        # the fractal's launches hand the tiles out in SQUARES of tiles that cover the frame with a margin (RowMap::unit_log2)
+                                        ("fractal", (3840, 2160)), ("fractal", (64, 64)), ("fractal", (1000, 40)), ("fractal", (8, 8)), ("fractal", (2050, 1030))])
 def test_persistent_hand_out_renders_every_pixel_once_the_order_exists(scene, size):
     import torch
     import sdf_playground_amd as sp
