@@ -617,7 +617,6 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
-	static constexpr bool square_units = true; // an object in the middle of the picture (sdfr_render_pixel.h): configuration 5g -1.9 %, at 4K with the start-up camera -5.7 %
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int retire_after = 2; // configuration 5g, one session (profiles/r03_launch_experiments.txt): 1.74 (8) / 1.68 (2) / 1.71 (1) ms
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)

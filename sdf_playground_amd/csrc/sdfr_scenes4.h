@@ -9,7 +9,6 @@ namespace sdfr {
 struct SceneTree
 {
 	static const char *name() { return "tree"; }
-	static constexpr bool square_units = true; // an object in the middle of the picture (sdfr_render_pixel.h): -1.7 % at 4K
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static constexpr int waves_per_simd = 5; // ~1900 instructions per evaluation: registers over residency (sdfr_pixel_kernel.h); 16.9 -> 15.7 ms at 4K
 	static constexpr bool persistent_tiles = true; // with waves that retire: 14.75 -> 14.25 ms at 4K
