@@ -346,8 +346,10 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	args.tile_cursors = mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, args);
 	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	// (the fold leaves frames with many rays per pixel in image order, SDFR_ROW_FEEDBACK_MAX_RAYS: a rule about tile ROWS -- their queue records
+	// are contiguous in image order --, not about squares, which scatter them either way)
 	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, !mode.persistent ? 0u : rows.unit_log2 ? rows.units : tiles_blocks / tiles_x,
-		(unsigned long long)n_work, rows.feedback_key);
+		rows.unit_log2 ? ~0ull >> 8 : (unsigned long long)n_work, rows.feedback_key);
 }
 
 template <class Scene, bool DBG>

@@ -88,8 +88,8 @@ struct PersistentTiles<Scene, typename VoidOf<decltype(Scene::persistent_tiles)>
 // A scene may say `static constexpr bool square_units = true;`: its persistent full-frame launches hand the tiles out in squares (RowMap::
 // unit_log2) instead of tile rows, dearest square first by the last frame's cost -- for a scene that is an object in the middle of the picture,
 // whose dear tiles sit in the middle of many rows (fractal: BASELINE configuration 4 1.174 -> 1.062 ms; the labyrinth +1.6 %, cube_sea +2.8 %,
-// lense with 8 lights +17 %: their cost runs along rows, and squares in image order scatter what rows keep together; gems and tree gain 2-3 %
-// from the squares and lose more by carrying the code: another register draw).
+// lense with 8 lights +13 ... +17 %: their cost runs along rows; gems with 8 lights 1.657 -> 1.563 ms; the tree gains 2 % from the squares and
+// loses 7 % by carrying the code: another register draw).
 template <class Scene, class = void>
 struct SquareUnits { static constexpr bool value = false; };
 template <class Scene>

@@ -617,6 +617,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr bool square_units = true; // the gems in the middle of the picture: with 8 lights and depth 4 their tiles render for 0.9 ms; first, not last: configuration 5g 1.657 -> 1.563 ms
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int retire_after = 2; // configuration 5g, one session (profiles/r03_launch_experiments.txt): 1.74 (8) / 1.68 (2) / 1.71 (1) ms
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
