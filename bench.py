@@ -258,8 +258,9 @@ def cpu_baseline(config=HEADLINE, width=None, height=None, max_seconds=20.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    # defaults: two sweeps of warm-up (row feedback, clocks: with 4 warm-up steps the 32 timed ones measured 1.2 % slower), four sweeps timed
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="BASELINE.json configuration (SURVEY.md 8d); 3 = the headline; 3r = --variant reflective")
     ap.add_argument("--variant", default="", choices=["", "reflective"],
                     help="reflective: config 3 with the labelled extension 'marble reflection_color 0.25' (BASELINE configs[2] as worded); never the headline")
@@ -269,7 +270,7 @@ def parse_args(argv=None):
                     help="march every step of every ray (sdfr_set_step_shortcuts off): the step counters then equal the reference's; the pixels are the same either way")
     ap.add_argument("--min-seconds", type=float, default=None,
                     help="N = 1: after the K timed steps keep looping the sweep for at least this long and report that steady-state figure beside "
-                         "the K-step one (`steady`): 32 steps are 40 ms, shorter than a clock ramp (default: 2 s; 0 with --no-extra-passes)")
+                         "the K-step one (`steady`): 64 steps are 80 ms, shorter than a clock ramp (default: 2 s; 0 with --no-extra-passes)")
     ap.add_argument("--no-extra-passes", action="store_true",
                     help="N = 1: skip the informational passes after the timed region (every step marched; the reference's own iter_count 100)")
     ap.add_argument("--no-second-pass", action="store_true",
