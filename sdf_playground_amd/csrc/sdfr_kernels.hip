@@ -207,6 +207,9 @@ hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks,
 	uint32_t feedback_rows, unsigned long long frame_pixels, uint32_t feedback_key)
 {
 	static const bool feedback = [] { const char *e = getenv("SDFR_TILE_FEEDBACK"); return e ? atoi(e) != 0 : true; }(); // developer knob
+	// developer knob: rays per pixel above which tile rows stay in image order (default SDFR_ROW_FEEDBACK_MAX_RAYS)
+	static const unsigned long long max_rays = [] { const char *e = getenv("SDFR_TILE_FEEDBACK_MAX_RAYS"); return e && atoi(e) > 0 ? (unsigned long long)atoi(e) : (unsigned long long)SDFR_ROW_FEEDBACK_MAX_RAYS; }();
+	if (frame_pixels < (~0ull >> 16)) frame_pixels = frame_pixels * max_rays / SDFR_ROW_FEEDBACK_MAX_RAYS;
 	uint32_t blocks = (n_blocks + SDFR_REDUCE_THREADS * 4 - 1) / (SDFR_REDUCE_THREADS * 4);
 	if (blocks > SDFR_REDUCE_BLOCKS) blocks = SDFR_REDUCE_BLOCKS;
 	if (blocks < 1) blocks = 1;
