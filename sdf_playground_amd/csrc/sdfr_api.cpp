@@ -593,7 +593,7 @@ int sdfr::render_impl(sdfr_renderer *r, int width, int height, int rank, int wor
 	RowMap rm;
 	rm.rank = rank;
 	rm.world = world;
-	rm.tile_w_log2 = r->tile_w_log2;
+	rm.tile_w_log2 = r->tile_w_log2 ? r->tile_w_log2 : scene_tile_w_log2(r->scene);
 	rm.priv_count = mode == RENDER_FULL ? 0 : r->priv_count;
 	rm.priv_period = mode == RENDER_FULL ? 1 : r->priv_period;
 	rm.direct = mode == RENDER_PRIVATE ? 1 : 0;

@@ -20,7 +20,7 @@ struct sdfr_renderer
 	sdfr::JitScene jit;
 	int schedule = SDFR_SCHEDULE_PIXEL; // the faster one on every measured scene
 	bool profiling = false;
-	int tile_w_log2 = 3;
+	int tile_w_log2 = 0; // 0: the scene's own tile shape (SceneTileShape, 8 x 8 unless it says otherwise); SDFR_TILE_W_LOG2 sets 3 .. 6
 	int launch_mode = 0; // sdfr_set_launch_mode
 	int priv_count = 0, priv_period = 1; // sdfr_set_strip_split
 	sdfr::FrameU U;

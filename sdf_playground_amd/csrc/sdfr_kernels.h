@@ -55,6 +55,7 @@ hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks,
 // RowMap::feedback_key of a launch: scene (index, or a hash of a run-time scene's name), frame width and what the row map selects
 uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm);
 int pixel_tile_cursor_words();
+int scene_tile_w_log2(int scene); // the tile shape a built-in scene asks for (SceneTileShape); 3 = 8 x 8, also for run-time scenes
 // how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per
 // tile.  launch_mode: 0 = the scene's own default (PersistentTiles), 1 = one wave per tile, 2 = persistent;
 // the developer knobs SDFR_PIXEL_PERSISTENT=0|1 and SDFR_PIXEL_BLOCKS_PER_CU=n (cap of a persistent grid) override.

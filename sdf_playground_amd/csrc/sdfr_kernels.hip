@@ -384,6 +384,17 @@ int device_cu_count(int device)
 SDFR_FOR_EACH_GROUP(SDFR_DECLARE_GROUP)
 #undef SDFR_DECLARE_GROUP
 
+int scene_tile_w_log2(int scene)
+{
+	switch (scene)
+	{
+#define SDFR_SHAPE(I, S) case I: return SceneTileShape<S>::value;
+		SDFR_FOR_EACH_SCENE(SDFR_SHAPE)
+#undef SDFR_SHAPE
+	default: return 3;
+	}
+}
+
 hipError_t launch_pixel_schedule(int scene, const FrameU &U, const RowMap &rows, void *out, int format, uint32_t *pixel_stats,
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, int launch_mode)
 {

@@ -617,6 +617,7 @@ struct SceneLense
 struct SceneGems
 {
 	static const char *name() { return "gems"; }
+	static constexpr int tile_w_log2 = 4; // 16 x 4 pixels per wave: configuration 5g 1.579 -> 1.517 ms (sdfr_render_pixel.h)
 	static constexpr bool square_units = true; // the gems in the middle of the picture: with 8 lights and depth 4 their tiles render for 0.9 ms; first, not last: configuration 5g 1.657 -> 1.563 ms
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int retire_after = 2; // configuration 5g, one session (profiles/r03_launch_experiments.txt): 1.74 (8) / 1.68 (2) / 1.71 (1) ms
