@@ -430,6 +430,7 @@ struct SceneFractal
 struct SceneLense
 {
 	static const char *name() { return "lense"; }
+	static constexpr int tile_w_log2 = 4; // 16 x 4 pixels per wave: 4.10 -> 3.98 ms at 4K, configuration 5 unchanged (sdfr_render_pixel.h)
 	static constexpr int waves_per_simd = 8; // the march loop fits 64 registers: BASELINE configuration 5 11.5 -> 11.05 ms (sdfr_pixel_kernel.h)
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
