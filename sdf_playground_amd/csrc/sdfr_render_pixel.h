@@ -96,8 +96,8 @@ template <class Scene>
 struct SquareUnits<Scene, typename VoidOf<decltype(Scene::square_units)>::type> { static constexpr bool value = Scene::square_units; };
 
 // The pixels of a wave: 8 x 8 unless the scene says `static constexpr int tile_w_log2 = n;` (a (1 << n) x (64 >> n) tile, n = 3 .. 6).  Measured
-// for every scene and configuration (profiles/r03_launch_experiments.txt): 8 x 8 is the best or within 1 % -- except gems with 8 lights and depth 4,
-// whose waves lose fewer lanes on 16 x 4 (BASELINE configuration 5g 1.579 -> 1.517 ms).
+// for every scene and configuration (profiles/r03_launch_experiments.txt): 8 x 8 is the best or within 1.5 % -- except gems with 8 lights and depth 4,
+// whose waves lose fewer lanes on 16 x 4 (BASELINE configuration 5g 1.579 -> 1.517 ms), and lense and neon at 4K (-3 %).
 template <class Scene, class = void>
 struct SceneTileShape { static constexpr int value = 3; };
 template <class Scene>
