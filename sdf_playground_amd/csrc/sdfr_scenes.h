@@ -329,7 +329,7 @@ struct SceneFractal
 {
 	static const char *name() { return "fractal"; }
 	static constexpr bool square_units = true; // an object in the middle of the picture: its dear tiles are handed out first (sdfr_render_pixel.h)
-	static constexpr int retire_after = 2; // its tiles are very uneven: configuration 4, round 3: 1.203 (1) / 1.178 (2) / 1.199 (4) / 1.366 (6) / 1.38 (8) ms
+	static constexpr int retire_after = 1; // its tiles are very uneven: configuration 4 with tile rows 1.203 (1) / 1.178 (2) / 1.199 (4) / 1.38 (8) ms, with the squares 1.044 (1) / 1.058 (2) / 1.070 (3) / 1.072 (4) / 1.19 (8)
 	static constexpr int waves_per_simd = 7; // configuration 4, round 3, one session: 1.26 (5) / 1.22 (6) / 1.196 (7) / 1.193 (8) ms
 	static constexpr bool persistent_tiles = true; // expensive, uneven tiles: resident waves pulling tiles win (sdfr_render_pixel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
@@ -621,7 +621,7 @@ struct SceneGems
 	static constexpr int tile_w_log2 = 4; // 16 x 4 pixels per wave: configuration 5g 1.579 -> 1.517 ms (sdfr_render_pixel.h)
 	static constexpr bool square_units = true; // the gems in the middle of the picture: with 8 lights and depth 4 their tiles render for 0.9 ms; first, not last: configuration 5g 1.657 -> 1.563 ms
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
-	static constexpr int retire_after = 2; // configuration 5g, one session (profiles/r03_launch_experiments.txt): 1.74 (8) / 1.68 (2) / 1.71 (1) ms
+	static constexpr int retire_after = 1; // configuration 5g with tile rows 1.74 (8) / 1.68 (2) / 1.71 (1) ms, with the squares 1.480 (1) / 1.505 (2) / 1.510 (3) / 1.562 (4) / 1.81 (8) (profiles/r03_launch_experiments.txt)
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
