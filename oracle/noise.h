@@ -1,7 +1,8 @@
 // oracle/noise.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
 //
-// Restates Engine/shader/noise.hlsl: PCG hash (:6-16), Ashima 3-D simplex noise
-// (:78-120 helpers, :205-300 snoise(float3)), turbulence (:473-476).
+// Restates Engine/shader/noise.hlsl: PCG hash (:6-16), Ashima simplex noise in 2, 3 and 4
+// dimensions (:78-120 helpers, :124-140 grad4, :142-203 snoise(float2), :205-300 snoise(float3),
+// :304-433 snoise(float4)), turbulence (:473-476).
 // Operation order follows the HLSL source expression by expression; dot() is the
 // fused helper of hlsl.h, everything else is unfused.
 #pragma once
@@ -25,11 +26,74 @@ inline real hashf(uint32_t input)
 
 // noise.hlsl:76-96
 inline real mod289(real x) { return x - r_floor(x * real(0.00346020761245674740484429065744f)) * real(289.0f); }
+inline float2 mod289(float2 x) { return float2(mod289(x.x), mod289(x.y)); }
 inline float3 mod289(float3 x) { return float3(mod289(x.x), mod289(x.y), mod289(x.z)); }
 inline float4 mod289(float4 x) { return float4(mod289(x.x), mod289(x.y), mod289(x.z), mod289(x.w)); }
 // noise.hlsl:101-120: mod289(x*x*34 + x)
 inline real permute(real x) { return mod289(x * x * real(34.0f) + x); }
+inline float3 permute(float3 x) { return float3(permute(x.x), permute(x.y), permute(x.z)); }
 inline float4 permute(float4 x) { return float4(permute(x.x), permute(x.y), permute(x.z), permute(x.w)); }
+
+// noise.hlsl:124-138 -- a hashed gradient on the 4-D cross polytope; `(p.w < 0)` is HLSL's bool -> 0 / 1
+inline float4 grad4(real j, float4 ip)
+{
+	const float4 ones = float4(1.0f, 1.0f, 1.0f, -1.0f);
+	float4 p;
+	float3 q = v_floor(v_frac(j * ip.xyz()) * real(7.0f)) * ip.z - real(1.0f);
+	p.x = q.x; p.y = q.y; p.z = q.z;
+	p.w = real(1.5f) - dot(v_abs(p.xyz()), ones.xyz());
+	const real neg = (p.w < real(0.f)) ? real(1.f) : real(0.f);
+	p.x = p.x - r_sign(p.x) * neg;
+	p.y = p.y - r_sign(p.y) * neg;
+	p.z = p.z - r_sign(p.z) * neg;
+	return p;
+}
+
+// noise.hlsl:144-201
+inline real snoise(float2 v)
+{
+	const float4 C = float4(
+		0.211324865405187f, // (3.0-sqrt(3.0))/6.0
+		0.366025403784439f, // 0.5*(sqrt(3.0)-1.0)
+		-0.577350269189626f, // -1.0 + 2.0 * C.x
+		0.024390243902439f); // 1.0 / 41.0
+
+	// first corner (:154-155)
+	float2 i = v_floor(v + dot(v, float2(C.y, C.y)));
+	float2 x0 = v - i + dot(i, float2(C.x, C.x));
+
+	// other corners (:163-165); i1 is an int2 in the source: 0 / 1, exact either way
+	float2 i1 = (x0.x > x0.y) ? float2(1.0f, 0.0f) : float2(0.0f, 1.0f);
+	float4 x12 = float4(x0.x, x0.y, x0.x, x0.y) + float4(C.x, C.x, C.z, C.z);
+	x12.x = x12.x - i1.x;
+	x12.y = x12.y - i1.y;
+
+	// permutations (:168-173)
+	i = mod289(i);
+	float3 p = permute(
+		permute(i.y + float3(real(0.0f), i1.y, real(1.0f)))
+		+ i.x + float3(real(0.0f), i1.x, real(1.0f)));
+
+	float3 m = v_max(real(0.5f) - float3(dot(x0, x0), dot(float2(x12.x, x12.y), float2(x12.x, x12.y)), dot(float2(x12.z, x12.w), float2(x12.z, x12.w))), real(0.0f));
+	m = m * m;
+	m = m * m;
+
+	// gradients: 41 points over a line, mapped onto a diamond (:189-192)
+	float3 x = real(2.0f) * v_frac(p * float3(C.w)) - real(1.0f);
+	float3 h = v_abs(x) - real(0.5f);
+	float3 ox = v_floor(x + real(0.5f));
+	float3 a0 = x - ox;
+
+	// approximate normalisation (:196)
+	m = m * (real(1.79284291400159f) - real(0.85373472095314f) * (a0 * a0 + h * h));
+
+	// noise value (:199-202)
+	float3 g;
+	g.x = a0.x * x0.x + h.x * x0.y;
+	g.y = a0.y * x12.x + h.y * x12.y;
+	g.z = a0.z * x12.z + h.z * x12.w;
+	return real(130.0f) * dot(m, g);
+}
 
 // noise.hlsl:205-300
 inline real snoise(float3 v)
@@ -98,6 +162,79 @@ inline real snoise(float3 v)
 	float4 m = v_max(real(0.6f) - float4(dot(x0, x0), dot(x1, x1), dot(x2, x2), dot(x3, x3)), real(0.0f));
 	m = m * m;
 	return real(42.0f) * dot(m * m, float4(dot(p0, x0), dot(p1, x1), dot(p2, x2), dot(p3, x3)));
+}
+
+// noise.hlsl:304-433
+inline real snoise(float4 v)
+{
+	const float4 C = float4(
+		0.138196601125011f, // (5 - sqrt(5))/20 G4
+		0.276393202250021f, // 2 * G4
+		0.414589803375032f, // 3 * G4
+		-0.447213595499958f); // -1 + 4 * G4
+
+	// first corner (:314-322)
+	float4 i = v_floor(v + dot(v, float4(real(0.309016994374947451f))));
+	float4 x0 = v - i + dot(i, float4(C.x));
+
+	// other corners: rank sorting (:327-335); step(edge, x) = x >= edge
+	float4 i0;
+	float3 isX = v_step(float3(x0.y, x0.z, x0.w), float3(x0.x, x0.x, x0.x));
+	float3 isYZ = v_step(float3(x0.z, x0.w, x0.w), float3(x0.y, x0.y, x0.z));
+	i0.x = isX.x + isX.y + isX.z;
+	i0.y = real(1.0f) - isX.x;
+	i0.z = real(1.0f) - isX.y;
+	i0.w = real(1.0f) - isX.z;
+	i0.y = i0.y + (isYZ.x + isYZ.y);
+	i0.z = i0.z + (real(1.0f) - isYZ.x);
+	i0.w = i0.w + (real(1.0f) - isYZ.y);
+	i0.z = i0.z + isYZ.z;
+	i0.w = i0.w + (real(1.0f) - isYZ.z);
+
+	// i0 now holds 0, 1, 2, 3 once each (:338-340)
+	float4 i3 = float4(r_saturate(i0.x), r_saturate(i0.y), r_saturate(i0.z), r_saturate(i0.w));
+	float4 i2 = float4(r_saturate(i0.x - real(1.0f)), r_saturate(i0.y - real(1.0f)), r_saturate(i0.z - real(1.0f)), r_saturate(i0.w - real(1.0f)));
+	float4 i1 = float4(r_saturate(i0.x - real(2.0f)), r_saturate(i0.y - real(2.0f)), r_saturate(i0.z - real(2.0f)), r_saturate(i0.w - real(2.0f)));
+
+	// (:347-350)
+	float4 x1 = x0 - i1 + float4(C.x);
+	float4 x2 = x0 - i2 + float4(C.y);
+	float4 x3 = x0 - i3 + float4(C.z);
+	float4 x4 = x0 + float4(C.w);
+
+	// permutations (:353-369)
+	i = mod289(i);
+	real j0 = permute(permute(permute(permute(i.w) + i.z) + i.y) + i.x);
+	float4 j1 = permute(
+		permute(
+			permute(
+				permute(i.w + float4(i1.w, i2.w, i3.w, real(1.0f)))
+				+ i.z + float4(i1.z, i2.z, i3.z, real(1.0f)))
+			+ i.y + float4(i1.y, i2.y, i3.y, real(1.0f)))
+		+ i.x + float4(i1.x, i2.x, i3.x, real(1.0f)));
+
+	// gradients: 7 x 7 x 6 points over a cube, mapped onto a 4-cross polytope (:373-384)
+	const float4 ip = float4(0.003401360544217687075f, 0.020408163265306122449f, 0.142857142857142857143f, 0.0f);
+	float4 p0 = grad4(j0, ip);
+	float4 p1 = grad4(j1.x, ip);
+	float4 p2 = grad4(j1.y, ip);
+	float4 p3 = grad4(j1.z, ip);
+	float4 p4 = grad4(j1.w, ip);
+
+	// normalise gradients (:387-397)
+	float4 norm = float4(r_rsqrt(dot(p0, p0)), r_rsqrt(dot(p1, p1)), r_rsqrt(dot(p2, p2)), r_rsqrt(dot(p3, p3)));
+	p0 = p0 * norm.x;
+	p1 = p1 * norm.y;
+	p2 = p2 * norm.z;
+	p3 = p3 * norm.w;
+	p4 = p4 * r_rsqrt(dot(p4, p4));
+
+	// mix the five corners (:400-432)
+	float3 m0 = v_max(real(0.6f) - float3(dot(x0, x0), dot(x1, x1), dot(x2, x2)), real(0.0f));
+	float2 m1 = v_max(real(0.6f) - float2(dot(x3, x3), dot(x4, x4)), real(0.0f));
+	m0 = m0 * m0;
+	m1 = m1 * m1;
+	return real(49.0f) * (dot(m0 * m0, float3(dot(p0, x0), dot(p1, x1), dot(p2, x2))) + dot(m1 * m1, float2(dot(p3, x3), dot(p4, x4))));
 }
 
 // noise.hlsl:473-476

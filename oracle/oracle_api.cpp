@@ -125,6 +125,11 @@ const std::vector<SceneEntry> &test_scenes()
 		{"debug_materials", "", {}, &ps_main<SceneDebugMaterials>},
 		{"normal_test", "VAR_round(min = 0.0001, max = 0.05, start = 0.01) VAR_analytic(min = 0, max = 1, step = 1, start = 1)", {"round", "analytic"},
 			&ps_main<SceneNormalTest>},
+		// the VAR_ tags of sdf_playground_amd/scenes/noise_lod.hlsl and dialect_tour.hlsl, in the order of the text
+		{"noise_lod", "VAR_lod(min = 0, max = 40, start = 9, step = 0.5) VAR_freq(min = 0.5, max = 8, start = 3) VAR_bump(min = 0, max = 0.05, start = 0.02)",
+			{"lod", "freq", "bump"}, &ps_main<SceneNoiseLod>},
+		{"dialect_tour", "VAR_spin(min = -2, max = 2, step = 0.1, start = 0.4) VAR_reach(min = 1, max = 3) VAR_blend(min = 0.01, max = 0.3, start = 0.08, steps = 7) "
+			"VAR_shine() VAR_shine(min = 0, max = 1, start = 0.3, step = 0.05)", {"spin", "reach", "blend", "shine"}, &ps_main<SceneDialectTour>},
 	};
 	return table;
 }
@@ -394,6 +399,23 @@ void orc_half_to_float(const unsigned short *in, float *out, long long n)
 	for (long long i = 0; i < n; ++i) out[i] = post::half_to_float(in[i]);
 }
 
+// the oracle's simplex noise, many points per call: what = 2 / 3 / 4 dimensions (in: n x what floats, out: n floats),
+// 5 = grad4 (in: n x 4 floats j, ip.xyz; out: n x 4)
+void orc_noise(int what, const float *in, float *out, long long n)
+{
+	for (long long k = 0; k < n; ++k)
+	{
+		if (what == 2) out[k] = val(snoise(float2(in[2 * k], in[2 * k + 1])));
+		else if (what == 3) out[k] = val(snoise(float3(in[3 * k], in[3 * k + 1], in[3 * k + 2])));
+		else if (what == 4) out[k] = val(snoise(float4(in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3])));
+		else if (what == 5)
+		{
+			float4 g = grad4(in[4 * k], float4(in[4 * k + 1], in[4 * k + 2], in[4 * k + 3], 0.0f));
+			out[4 * k] = val(g.x); out[4 * k + 1] = val(g.y); out[4 * k + 2] = val(g.z); out[4 * k + 3] = val(g.w);
+		}
+	}
+}
+
 // Known-answer access to individual library functions (tests/test_oracle_*.py).
 // Returns the number of outputs written, or -1 for an unknown function.
 int orc_kat(const char *fn, const float *in, float *out)
@@ -437,6 +459,11 @@ int orc_kat(const char *fn, const float *in, float *out)
 	if (f == "hash") { uint32_t u; memcpy(&u, &in[0], 4); uint32_t h = hash(u); memcpy(&out[0], &h, 4); return 1; }
 	if (f == "hashf") { uint32_t u; memcpy(&u, &in[0], 4); out[0] = val(hashf(u)); return 1; }
 	if (f == "snoise3") { out[0] = val(snoise(v3(0))); return 1; }
+	if (f == "snoise2") { out[0] = val(snoise(float2(in[0], in[1]))); return 1; }
+	if (f == "snoise4") { out[0] = val(snoise(float4(in[0], in[1], in[2], in[3]))); return 1; }
+	if (f == "grad4") { float4 g = grad4(in[0], float4(in[1], in[2], in[3], in[4])); out[0] = val(g.x); out[1] = val(g.y); out[2] = val(g.z); out[3] = val(g.w); return 4; }
+	if (f == "permute") { out[0] = val(permute(real(in[0]))); return 1; }
+	if (f == "mod289") { out[0] = val(mod289(real(in[0]))); return 1; }
 	if (f == "turbulence") { out[0] = val(turbulence(v3(0))); return 1; }
 	if (f == "tile_color") { float4 c = tile_color_from_pos(float2(in[0], in[1])); out[0] = val(c.x); out[1] = val(c.y); out[2] = val(c.z); out[3] = val(c.w); return 4; }
 	if (f == "sky_color") return put3(sky_color(v3(0), in[3]));

@@ -129,6 +129,9 @@ std::string hlsl_scene_class_body(const std::string &hlsl)
 	// D3D's float -> int casts saturate: `(int)(expr)` / `(uint)(expr)`
 	t = std::regex_replace(t, std::regex(R"(\(\s*int\s*\)\s*\()"), "ftoi_(");
 	t = std::regex_replace(t, std::regex(R"(\(\s*uint\s*\)\s*\()"), "ftou_(");
+	// ... and in front of a bare operand: `(int)cell.x`, `(uint)index` (a name with its members; not a call, not an element)
+	t = std::regex_replace(t, std::regex(R"(\(\s*int\s*\)\s*([A-Za-z_]\w*(?:\.\w+)*)(?![\w.(\[]))"), "ftoi_($1)");
+	t = std::regex_replace(t, std::regex(R"(\(\s*uint\s*\)\s*([A-Za-z_]\w*(?:\.\w+)*)(?![\w.(\[]))"), "ftou_($1)");
 	t = std::regex_replace(t, std::regex(R"(\bhalf([1-4]?)\b)"), "float$1");
 	return float_literals(t);
 }

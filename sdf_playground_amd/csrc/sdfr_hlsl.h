@@ -21,11 +21,11 @@
 //     (pshader_sdf.hlsl:17-36: eye, front_vec, right_vec, top_vec, stime, the five epsilons), pi / tau / sqrt_half / sqrt_two;
 //   * the shader libraries under their HLSL names (sdf_primitives / sdf_ops / sdf_common / sdf_materials / noise: sdSphere ...
 //     turbulence), each a thin wrapper of the function the built-in scenes use (sdfr_lib.h, sdfr_noise.h) -- so a scene
-//     loaded this way and the same scene compiled ahead of time render the same bits.  Not provided: snoise(float2) and
-//     snoise(float4) (no scene of the reference uses them).
+//     loaded this way and the same scene compiled ahead of time render the same bits.  All three snoise overloads,
+//     grad4, mod289 and permute of noise.hlsl are there.
 // SceneAdapter<UserScene> then presents the class to the pixel kernel as any other scene (dist / material / normal / lights /
-// background).  GeometryInput.camera_distance and the ray offsets are the hit's in material, normal and light calls and 0
-// during geometry steps (no scene of the reference reads them there).
+// background).  A geometry step sees the GeometryInput the reference hands it: the sample's running camera_distance and the
+// pixel's ray offsets (SceneReadsMarchState, sdfr_pixel.h).
 #pragma once
 #include "sdfr_pixel.h"
 #include "sdfr_hlsl_swizzles.h"
@@ -466,16 +466,19 @@ struct SceneAdapter
 		m.use_hdr = false;
 		return m;
 	}
-	// map(..., geometry_step = true), as map_geometry calls it (pshader_sdf.hlsl:111-135)
-	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
+	// map(..., geometry_step = true), as map_geometry calls it (pshader_sdf.hlsl:111-135), with the GeometryInput the reference
+	// hands it: the running camera_distance of the sample and the pixel's ray offsets (:187-218, 297-302); the three samples
+	// of the normal carry the hit's (:164-177)
+	static constexpr bool geometry_reads_march_state = true;
+	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast, const GeoStep &gs)
 	{
 		S scene(U);
 		GeometryInput g;
 		g.pos = float3(p);
 		g.dir = float4(float3(dir), fast ? 1.f : 0.f);
-		g.camera_distance = 0.f;
-		g.right_ray_offset = float3(0.f);
-		g.bottom_ray_offset = float3(0.f);
+		g.camera_distance = gs.camera_distance;
+		g.right_ray_offset = float3(gs.right_off);
+		g.bottom_ray_offset = float3(gs.bottom_off);
 		MarchingInput march;
 		march.is_inside = false;
 		march.last_transparent_pos = float3(R.flags.last_transparent_pos);

@@ -2,7 +2,7 @@
 // reference's dialect (included inside the class body by the translation unit sdfr_hlsl.cpp generates, so that a scene's own
 // functions overload them, as they do in HLSL, instead of hiding them).  Each is a thin wrapper of the function the built-in
 // scenes use (sdfr_lib.h, sdfr_noise.h): same arithmetic, same bits.
-//   sdf_primitives.hlsl:6-131   sdf_ops.hlsl:6-134   sdf_common.hlsl:4-94   sdf_materials.hlsl:6-201   noise.hlsl:6-16,205-300,473-476
+//   sdf_primitives.hlsl:6-131   sdf_ops.hlsl:6-134   sdf_common.hlsl:4-94   sdf_materials.hlsl:6-201   noise.hlsl:6-16,76-476
 
 // ---- primitives ----
 SDF_HD float sdSphere(float3 pos, float radius) const { return sd_sphere(pos, radius); }
@@ -107,5 +107,15 @@ SDF_HD float coordinate_material(float3 pos, float3 norm, float width) const { r
 SDF_HD uint hash(uint input) const { return pcg_hash(input); }
 SDF_HD float hashf(uint input) const { return pcg_hashf(input); }
 SDF_HD float hashf(int input) const { return pcg_hashf((uint)input); }
+SDF_HD float mod289(float x) const { return noise_mod289(x); }
+SDF_HD float2 mod289(float2 x) const { return float2(noise_mod289(x.x), noise_mod289(x.y)); }
+SDF_HD float3 mod289(float3 x) const { return float3(noise_mod289(x.x), noise_mod289(x.y), noise_mod289(x.z)); }
+SDF_HD float4 mod289(float4 x) const { return float4(noise_mod289(x.x), noise_mod289(x.y), noise_mod289(x.z), noise_mod289(x.w)); }
+SDF_HD float permute(float x) const { return noise_permute(x); }
+SDF_HD float3 permute(float3 x) const { return float3(noise_permute(x.x), noise_permute(x.y), noise_permute(x.z)); }
+SDF_HD float4 permute(float4 x) const { return float4(noise_permute(x.x), noise_permute(x.y), noise_permute(x.z), noise_permute(x.w)); }
+SDF_HD float4 grad4(float j, float4 ip) const { return float4(noise_grad4(j, ip.x, ip.y, ip.z)); }
+SDF_HD float snoise(float2 v) const { return snoise2(v); }
 SDF_HD float snoise(float3 v) const { return snoise3(v); }
+SDF_HD float snoise(float4 v) const { return snoise4(v); }
 SDF_HD float turbulence(float3 pos) const { return turbulence3(pos); }

@@ -120,6 +120,42 @@ SDF_HD float map_geometry(const FrameU &U, const DebugFlags &F, const typename S
 	return d;
 }
 
+// ---- the march state a scene's geometry step may look at (pshader_sdf.hlsl:187-218, 297-302) -----------------------
+// In the reference a geometry step sees the whole GeometryInput: the running camera_distance of the sample and the pixel's
+// ray offsets besides position and direction.  No scene of the reference reads them there, and the scenes compiled ahead of
+// time take (p, dir) only.  A scene that declares `static constexpr bool geometry_reads_march_state = true` (what scenes in
+// the reference's dialect get, sdfr_hlsl.h) has `dist` called with a sixth argument instead; for every other scene none of
+// this exists in the generated code.
+struct GeoStep
+{
+	float camera_distance;       // geometry.camera_distance at this sample (the hit's, for the normal's samples)
+	vec3 right_off, bottom_off;  // geometry.right_ray_offset / bottom_ray_offset: the pixel's, for every ray of the pixel
+};
+template <bool B>
+struct VoidIf {};
+template <>
+struct VoidIf<true> { typedef void type; };
+template <class Scene, class = void>
+struct SceneReadsMarchState { static constexpr bool value = false; };
+template <class Scene>
+struct SceneReadsMarchState<Scene, typename VoidIf<Scene::geometry_reads_march_state>::type> { static constexpr bool value = true; };
+
+template <class Scene, bool DBG>
+SDF_HD float map_geometry_at(const FrameU &U, const DebugFlags &F, const typename Scene::RayInv &R, vec3 p, vec3 dir, bool fast, const GeoStep &gs)
+{
+	if (!DBG)
+		return Scene::dist(U, R, p, dir, fast, gs);
+	float d = 3e38f;
+	if (F.show_on)
+		d = Scene::dist(U, R, p, dir, fast, gs);
+	if (F.plane_on)
+	{
+		float plane = sd_plane_fast(p - V3(U.debug_x, U.debug_y, U.debug_z), dir, fast, U.debug_normal);
+		return min1(d, plane);
+	}
+	return d;
+}
+
 // ---- sphere tracing with over-relaxation (pshader_sdf.hlsl:179-220) as a resumable state ----
 struct March
 {
@@ -325,7 +361,17 @@ SDF_HD void map_material(const FrameU &U, const DebugFlags &F, const SurfacePoin
 		nf.is_shadow = false;
 		nf.last_transparent_pos = V3s(0.f);
 		typename Scene::RayInv R0 = Scene::ray_setup(U, sp.dir, nf);
-		float d = Scene::dist(U, R0, sp.pos, sp.dir, false);
+		float d;
+		if constexpr (SceneReadsMarchState<Scene>::value)
+		{
+			GeoStep gs;
+			gs.camera_distance = sp.camera_distance;
+			gs.right_off = sp.right_off;
+			gs.bottom_off = sp.bottom_off;
+			d = Scene::dist(U, R0, sp.pos, sp.dir, false, gs);
+		}
+		else
+			d = Scene::dist(U, R0, sp.pos, sp.dir, false);
 		m.id = MAT_DISTANCE_PLANE;
 		m.prop_x = d / U.debug_scale;
 	}

@@ -196,7 +196,18 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 				status = MARCH_MISS; // what the remaining steps would come to
 				break;
 			}
-			float d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
+			float d;
+			if constexpr (SceneReadsMarchState<Scene>::value)
+			{
+				const PixelRay pr = store.pixel_ray_kept();
+				GeoStep gs;
+				gs.camera_distance = m.t;
+				gs.right_off = pr.right_ray;
+				gs.bottom_off = pr.bottom_ray;
+				d = map_geometry_at<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true, gs) * inside_sign;
+			}
+			else
+				d = map_geometry<Scene, DBG>(U, F, R, march_pos(m), ray.dir, true) * inside_sign;
 			cnt.march_evals++;
 			if (escaped && !((m.last_d + d) < m.last_d * m.factor))
 			{
@@ -236,9 +247,25 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 				if (!no.use_normal)
 				{
 					const float baseline = m.d * inside_sign;
-					float g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, no.sample_dist), ray.dir, false) - baseline;
-					float g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, no.sample_dist), ray.dir, false) - baseline;
-					float g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, no.sample_dist), ray.dir, false) - baseline;
+					float g0, g1, g2;
+					if constexpr (SceneReadsMarchState<Scene>::value)
+					{
+						// grad() works on the hit's GeometryInput: its camera_distance and offsets stay (pshader_sdf.hlsl:164-177)
+						const PixelRay pr = store.pixel_ray_kept();
+						GeoStep gs;
+						gs.camera_distance = hit.t;
+						gs.right_off = pr.right_ray;
+						gs.bottom_off = pr.bottom_ray;
+						g0 = map_geometry_at<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, no.sample_dist), ray.dir, false, gs) - baseline;
+						g1 = map_geometry_at<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, no.sample_dist), ray.dir, false, gs) - baseline;
+						g2 = map_geometry_at<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, no.sample_dist), ray.dir, false, gs) - baseline;
+					}
+					else
+					{
+						g0 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 0, no.sample_dist), ray.dir, false) - baseline;
+						g1 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 1, no.sample_dist), ray.dir, false) - baseline;
+						g2 = map_geometry<Scene, DBG>(U, F, R, grad_sample_pos(hit.pos, 2, no.sample_dist), ray.dir, false) - baseline;
+					}
 					hit.normal = normalize(V3(g0, g1, g2));
 				}
 			}

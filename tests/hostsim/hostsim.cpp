@@ -92,6 +92,23 @@ extern "C" float hostsim_math(int fn, float a, float b)
 	}
 }
 
+// the product's simplex noise, many points per call: what = 2 / 3 / 4 dimensions (in: n x what floats, out: n floats),
+// 5 = grad4 (in: n x 4 floats j, ip.xyz; out: n x 4)
+extern "C" void hostsim_noise(int what, const float *in, float *out, long long n)
+{
+	for (long long k = 0; k < n; ++k)
+	{
+		if (what == 2) out[k] = snoise2(V2(in[2 * k], in[2 * k + 1]));
+		else if (what == 3) out[k] = snoise3(V3(in[3 * k], in[3 * k + 1], in[3 * k + 2]));
+		else if (what == 4) out[k] = snoise4(V4(in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3]));
+		else if (what == 5)
+		{
+			const vec4 g = noise_grad4(in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3]);
+			out[4 * k] = g.x; out[4 * k + 1] = g.y; out[4 * k + 2] = g.z; out[4 * k + 3] = g.w;
+		}
+	}
+}
+
 // Numerical check of the bounding-ball lower bounds the labyrinth functor culls with
 // (sdfr_scenes.h): returns the number of sampled points that violate a bound.
 extern "C" long long hostsim_check_labyrinth_bounds(long long n, unsigned seed)

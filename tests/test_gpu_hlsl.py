@@ -92,3 +92,45 @@ def test_a_broken_scene_leaves_the_loaded_one_in_place():
         assert r.currentScene() == "fast_sphere"  # SceneManager.cpp:118-127: the old shader stays
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("scene", ["noise_lod", "dialect_tour"])
+def test_dialect_scene_on_the_gpu_renders_its_oracle_twin_s_bits(oracle, scene):
+    """Builder-written scenes in the reference's dialect, compiled by hiprtc and run by the pixel kernel, against their oracle
+    twins (oracle/test_scenes.h) -- HIP against the oracle, not HIP against HIP.  noise_lod: snoise(float2), snoise(float4),
+    grad4, and a geometry step that reads geometry.camera_distance and the ray offsets (pshader_sdf.hlsl:187-218).
+    dialect_tour: swizzled l-values and swaps, an inout swizzle, float3x3 + mul, static const initialisers, (int) with D3D's
+    saturation, a scene-local voronoi overload, opRepLim / opShell / smin, and every VAR_ tag quirk."""
+    import sdf_playground_amd as sp
+    from test_hlsl_cpu import TWIN_CAMS, TWIN_CASES, twin_frame
+
+    r = sp.SDFRenderer(0)
+    try:
+        r.initShaderHlsl(scene, os.path.join(SCENES_DIR, scene + ".hlsl"))
+        table = {row[0]: row for row in oracle.var_table(scene)}
+        got = {v.name: (v.minval, v.maxval, v.start, v.step) for v in r.getVariableMap().values()}
+        assert list(got) == sorted(table)  # std::map order
+        for name, row in table.items():
+            assert got[name] == tuple(np.float32(x) for x in row[1:5]), name
+        limit_keys = ("max_cost_default", "extension_lights")
+        for cam, extra in zip(TWIN_CAMS, TWIN_CASES[scene]):
+            f = twin_frame(oracle, scene, cam, w=W, h=H, **extra)
+            ref, rst, _ = oracle.render(scene, f, stats=True)
+            c = sp.Camera()
+            c.SetEye(cam[0])
+            c.SetLookat(cam[1])
+            c.SetAspect(float(np.float32(W) / np.float32(H)))
+            r.setParameters(extra.get("stime", 0.7))
+            r.resetVariables()
+            r.setLimits(iter_count=100, max_cost_default=7, extension_lights=0)
+            r.setLimits(**{k: v for k, v in extra.items() if k in limit_keys})
+            for k, v in extra.items():
+                if k not in limit_keys and k != "stime":
+                    assert r.setValue(k, v), k
+            for shortcuts in (False, True):
+                r.setStepShortcuts(shortcuts)
+                img, st = r.render(c, W, H, pixel_stats=True)
+                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (scene, cam, extra, int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()))
+                assert np.array_equal(st, rst), (scene, cam, extra)
+    finally:
+        r.close()

@@ -152,3 +152,84 @@ def test_pendulum_hlsl_equals_its_cpp_twin():
         b, sb = hostsim.render_scene_source(LC, f)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(sa, sb)
         assert (sa[..., 0] >= 2).sum() > 200  # the mirror ball and the shadow rays are in the picture
+
+
+# cameras for the two dialect scenes with oracle twins: (eye, lookat)
+TWIN_CAMS = [((0.0, 2.0, -5.0), (0.0, 1.0, 0.0)), ((4.5, 1.2, -3.5), (0.5, 0.8, 0.5)), ((-3.0, 4.0, 4.5), (0.0, 0.6, 1.0)), ((0.3, 0.4, -14.0), (0.0, 1.0, 0.0))]
+
+
+def twin_frame(oracle, scene, cam, w=96, h=64, stime=0.7, **extra):
+    f = oracle.default_frame(scene, w, h, basis=oracle.camera_lookat(cam[0], cam[1], FOVY, np.float32(w) / np.float32(h)), stime=stime)
+    slots = {r[0]: r[6] for r in oracle.var_table(scene)}
+    for k, v in extra.items():
+        if k in slots:
+            if slots[k] >= 0:
+                f.scene_var[slots[k]] = v
+            else:
+                setattr(f, k, v)
+        else:
+            setattr(f, k, v)
+    return f
+
+
+TWIN_CASES = {
+    # 2-D / 4-D simplex noise, grad4; camera_distance and the ray offsets read in the geometry step (pshader_sdf.hlsl:187-218)
+    "noise_lod": [dict(), dict(lod=3.0, freq=6.5, bump=0.04), dict(lod=40.0, stime=3.9, max_cost_default=9), dict(debug_ny=1.0, debug_y=0.8)],
+    # swizzled l-values, inout swizzles, float3x3 + mul, static const initialisers, saturating (int), a voronoi overload, VAR_ quirks
+    "dialect_tour": [dict(), dict(spin=-1.3, reach=2.7, blend=0.25, shine=0.8), dict(stime=5.2, extension_lights=5, max_cost_default=9), dict(debug_nx=1.0, debug_x=0.3)],
+}
+
+
+@pytest.mark.parametrize("scene", sorted(TWIN_CASES))
+def test_dialect_scene_renders_its_oracle_twin_s_bits(oracle, scene):
+    import hostsim
+
+    text = open(os.path.join(SCENES_DIR, scene + ".hlsl")).read()
+    L, slots = hostsim.build_hlsl(scene, text)
+    table = oracle.var_table(scene)
+    assert slots == [r[0] for r in sorted(table, key=lambda r: r[6]) if r[6] >= 0]
+    # the table the library parses from the text is the one the oracle parses from the same tags (ShaderUtil.cpp:122-191)
+    parsed = oracle.parse_vars(text)
+    for name, mn, mx, start, step, _v, slot in table:
+        if slot >= 0:
+            assert parsed[name][:4] == (mn, mx, start, step), name
+    hits = 0
+    for cam, extra in zip(TWIN_CAMS, TWIN_CASES[scene]):
+        f = twin_frame(oracle, scene, cam, **extra)
+        ref, rst, _ = oracle.render(scene, f, stats=True)
+        img, st = hostsim.render_hlsl(L, hostsim.frame_from_oracle(f))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (scene, cam, extra, int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()))
+        assert np.array_equal(st, rst), (scene, cam, extra)
+        hits += int(rst[..., 2].sum())
+    assert hits > 5000
+
+
+def test_builder_written_dialect_scenes_compile_for_gfx950():
+    import sdf_playground_amd as sp
+
+    for name in ("pendulum", "rounded", "noise_lod", "dialect_tour"):
+        ok, log = sp.check_scene_hlsl(open(os.path.join(SCENES_DIR, name + ".hlsl")).read())
+        assert ok, (name, log[-2000:])
+
+
+def test_geometry_step_sees_the_march_state(oracle):
+    """noise_lod's picture depends on geometry.camera_distance and the ray offsets DURING the march: with `lod` below the ball's
+    distance the bump is gone, and the ring is thicker than its 1-cm tube wherever a pixel is wider than that"""
+    f_near = twin_frame(oracle, "noise_lod", TWIN_CAMS[0], lod=40.0)
+    f_far = twin_frame(oracle, "noise_lod", TWIN_CAMS[0], lod=0.0)
+    a, _, _ = oracle.render("noise_lod", f_near)
+    b, _, _ = oracle.render("noise_lod", f_far)
+    assert (np.abs(a - b).max(axis=2) > 1e-3).mean() > 0.02
+    # far away the ring would fall between the pixels without the footprint term; with it the ring still collects hits
+    f = twin_frame(oracle, "noise_lod", ((-2.4, 1.0, -30.0), (-2.4, 1.0, 0.3)), w=120, h=80)
+    _, st, _ = oracle.render("noise_lod", f, stats=True)
+    ring_rows = st[30:50, 40:80, 2]
+    assert ring_rows.sum() > 20
+
+
+def test_bare_integer_casts_are_translated():
+    import sdf_playground_amd as sp
+
+    t = sp.translate_scene_hlsl("void map_normal(GeometryInput g, inout NormalOutput o) { int a = (int)cell.x; uint b = (uint) index; int c = (int)f(x); int d = (int)(y); int e = (int)v[2]; }")
+    assert "int a = ftoi_(cell.x);" in t and "uint b = ftou_(index);" in t and "int d = ftoi_(y);" in t
+    assert "(int)f(x)" in t and "(int)v[2]" in t  # calls and elements keep the C cast
