@@ -282,12 +282,11 @@ def parse_args(argv=None):
     ap.add_argument("--private-strips", default="auto",
                     help="N > 1: of every 16 strips, how many rank 0 renders privately (its pixels do not travel); 'auto' = the fastest of a few "
                          "candidates timed during start-up")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "gloo", "ipc"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "gloo"],
                     help="N > 1: rccl = the library's own gather (sdfr_render_gather); torch = torch.distributed.gather of the same strips "
                          "(also taken, on every rank, when the library's communicator cannot be made); gloo = the same strips staged "
                          "through host memory and gathered over gloo -- slow, for rehearsing N ranks where RCCL cannot run, e.g. several "
-                         "ranks on ONE GPU (RCCL refuses two ranks on a device); never a result; ipc = EXPERIMENTAL: no collective library, "
-                         "peers copy their strips into rank 0's buffer through hipIpc mappings (sdfr_render_gather_peer), control over gloo")
+                         "ranks on ONE GPU (RCCL refuses two ranks on a device); never a result")
     ap.add_argument("--wire", default="f16", choices=["f16", "f32"],
                     help="N > 1: f16 = strips and image in the reference's RGBA16F target format (7 B/pixel on the links); f32 = lossless fp32 (13 B/pixel)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="N > 1: handles / streams the frames alternate between")
@@ -478,14 +477,13 @@ def run(a, world):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        if a.transport in ("gloo", "ipc"):
+        if a.transport == "gloo":
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     host_staged = distributed and a.transport == "gloo"
-    peer_copy = distributed and a.transport == "ipc"
-    ctl = "cpu" if (host_staged or peer_copy) else "cuda"   # where the control tensors of the collectives live
+    ctl = "cpu" if host_staged else "cuda"   # where the control tensors of the collectives live
     W, H = a.width or cfg["width"], a.height or cfg["height"]
     scene = cfg["scene"]
     schedule = {"auto": sp.SCHEDULE_PIXEL, "wavefront": sp.SCHEDULE_WAVEFRONT, "pixel": sp.SCHEDULE_PIXEL}[a.schedule]
@@ -555,17 +553,7 @@ def run(a, world):
                 if comm is not None:
                     comm.close()
                     comm = None
-        if peer_copy:
-            # one region per handle: rank 0 allocates it for the largest share (no private strips) and exports it
-            transport = "sdfr_render_gather_peer (EXPERIMENTAL: hipIpc mappings, peers copy into rank 0's buffer; no collective library)"
-            cap = world * sp.strip_buffer_bytes(W, H, world, wire_fmt, (0, SPLIT_PERIOD))
-            descs = [rr[b].peerRegionCreate(cap, world) for b in range(depth)] if rank == 0 else [None] * depth
-            dist.broadcast_object_list(descs, src=0)
-            if rank != 0:
-                for b in range(depth):
-                    rr[b].peerRegionOpen(descs[b])
-            dist.barrier()
-        if comm is None and not peer_copy:
+        if comm is None:
             side = torch.cuda.Stream()
             r_asm = r_priv = None
             if rank == 0:
@@ -579,9 +567,9 @@ def run(a, world):
 
         def set_split(sp_split):
             nonlocal local, gathered_flat, gather_lists
-            for h_ in rr + (([r_asm] + r_priv) if (comm is None and not peer_copy and rank == 0) else []):
+            for h_ in rr + (([r_asm] + r_priv) if (comm is None and rank == 0) else []):
                 h_.setStripSplit(*sp_split)
-            if comm is None and not peer_copy:
+            if comm is None:
                 torch.cuda.synchronize()
                 nb = sp.strip_buffer_bytes(W, H, world, wire_fmt, sp_split)
                 local = [torch.empty((nb,), dtype=torch.uint8, device="cuda") for _ in range(depth)]
@@ -602,9 +590,6 @@ def run(a, world):
         h.setCamera(cam)
         if comm is not None:
             h.renderGather(comm, W, H, out=images[b] if rank == 0 else None, fmt=img_fmt, wire=wire_fmt)
-            return [h]
-        if peer_copy:
-            h.renderGatherPeer(rank, world, W, H, out=images[b] if rank == 0 else None, fmt=img_fmt, wire=wire_fmt)
             return [h]
         used = [h]
         if host_staged:
@@ -722,7 +707,7 @@ def run(a, world):
                 if name.startswith("gather transfer"):
                     xfer_ms.append(ms)
                     xfer_bytes = int(name.split()[2])
-        if distributed and (comm is not None or peer_copy):
+        if distributed and comm is not None:
             if scratch is None:
                 scratch = torch.empty((sp.strip_buffer_bytes(W, H, world, wire_fmt, split),), dtype=torch.uint8, device="cuda")
             hs[0].renderStrips(W, H, rank, world, scratch, fmt=wire_fmt)
@@ -838,7 +823,7 @@ def run(a, world):
         if distributed:
             out["config"].update({
                 "transport": ("sdfr_render_gather (RCCL ncclSend/ncclRecv inside libsdfr.so)" if comm is not None else
-                              (str(transport) if peer_copy else "torch.distributed.gather: " + str(transport))),
+                              "torch.distributed.gather: " + str(transport)),
                 "wire_format": "SDFR_STRIP_RGB16F_A8 (7 B/pixel)" if wire16 else "SDFR_STRIP_RGB32F_A8 (13 B/pixel)",
                 "image": "RGBA16F on rank 0 (the reference's render-target format, Postprocessing.cpp:23)" if wire16 else "RGBA32F on rank 0",
                 "frames_in_flight": depth,
@@ -1002,17 +987,8 @@ def run(a, world):
         watchdog.daemon = True
         watchdog.start()
         torch.cuda.synchronize()
-        if peer_copy:
-            stage[0] = "sdfr_peer_region_status"
-            for h_ in rr:
-                h_.peerRegionStatus()   # raises if a wait gave up
         stage[0] = "dist.barrier (before teardown)"
         dist.barrier()
-        if peer_copy:
-            stage[0] = "sdfr_peer_region_close"
-            for h_ in (rr if rank != 0 else []):
-                h_.peerRegionClose()    # the peers unmap before rank 0 frees
-            dist.barrier()
         faulthandler.cancel_dump_traceback_later()
         stage[0] = "sdfr_destroy (extra handles)"
         for h_ in rr[1:]:

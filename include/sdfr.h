@@ -36,7 +36,8 @@ typedef enum sdfr_status
 	SDFR_ERR_HIP = -5,
 	SDFR_ERR_NO_DEVICE = -6,
 	SDFR_ERR_COMPILE = -7, /* a run-time scene does not compile: sdfr_last_error holds the compiler's messages */
-	SDFR_ERR_COMM = -8     /* RCCL could not be loaded, or one of its calls failed: sdfr_comm_last_error / sdfr_last_error */
+	SDFR_ERR_COMM = -8,    /* RCCL could not be loaded, or one of its calls failed: sdfr_comm_last_error / sdfr_last_error */
+	SDFR_ERR_INTERNAL = -9 /* a C++ exception (out of memory, ...) was caught at the C boundary: sdfr_last_error has its words; never an abort */
 } sdfr_status;
 
 /* ---- lifetime: SDFRenderer::init(Graphics&) (SDFRenderer.cpp:9-25) ----------------------- */
@@ -274,25 +275,6 @@ int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, vo
 /* the same for the n handles / communicators of ONE process (sdfr_comm_create_all), rank i = index i */
 int sdfr_render_gather_all(sdfr_renderer *const *r, sdfr_comm *const *c, int n, int width, int height, void *root_image, int image_format,
 	int wire_format);
-
-/* ---- the same gather without a collective library: peers COPY their strips straight into rank 0's buffer
- *      through hipIpc mappings (one process per GPU, or several processes on one GPU), flag words in rank 0's
- *      memory say when a rank's strips have arrived and when rank 0 has assembled them.  EXPERIMENTAL: exercised
- *      with several processes on one GPU only; its behaviour across xGMI is unmeasured.
- *        rank 0:  sdfr_peer_region_create(r, capacity_bytes, world, descriptor)   allocates the gathered buffer
- *                 (capacity >= world * sdfr_strip_buffer_bytes(...)) and the flags, exports both
- *        peers:   sdfr_peer_region_open(r, descriptor)                            maps them (the caller moves the
- *                 SDFR_PEER_REGION_BYTES bytes of the descriptor from rank 0 to the peers by its own means)
- *        all:     sdfr_render_gather_peer(r, rank, world, width, height, root_image, image_format, wire_format)
- *                 once per frame on every rank, same arguments, same order; like sdfr_render_gather otherwise
- *        sdfr_peer_region_status(r): SDFR_OK, or SDFR_ERR_COMM if a wait gave up (a rank did not arrive within 2 s)
- *      One region per handle; two frames in flight = two handles with a region each. --------------------- */
-#define SDFR_PEER_REGION_BYTES 160
-int sdfr_peer_region_create(sdfr_renderer *r, size_t capacity_bytes, int world, void *descriptor_out);
-int sdfr_peer_region_open(sdfr_renderer *r, const void *descriptor);
-int sdfr_peer_region_close(sdfr_renderer *r);
-int sdfr_peer_region_status(sdfr_renderer *r);
-int sdfr_render_gather_peer(sdfr_renderer *r, int rank, int world, int width, int height, void *root_image, int image_format, int wire_format);
 
 /* ---- the consumer of the render target: HDR::process
  *      (Postprocessing.cpp:130-174; bloom.hlsl; pshader_hdr.hlsl).  scene = the RGBA16F frame of

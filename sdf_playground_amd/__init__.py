@@ -31,12 +31,11 @@ RGBA16F = 1
 STRIP_RGB32F_A8 = 2  # strips only: rgb float triples + one flag byte per pixel (lossless, 13 B/pixel)
 STRIP_RGB16F_A8 = 3  # strips only: rgb half triples + one flag byte per pixel (the reference's RGBA16F target in 7 B/pixel)
 COMM_ID_BYTES = 128
-PEER_REGION_BYTES = 160
 STRIP_ROWS = 8
 
 _STATUS = {
     0: "SDFR_OK", -1: "SDFR_ERR_INVALID_ARGUMENT", -2: "SDFR_ERR_UNKNOWN_SCENE", -3: "SDFR_ERR_UNKNOWN_VARIABLE",
-    -4: "SDFR_ERR_NO_SCENE", -5: "SDFR_ERR_HIP", -6: "SDFR_ERR_NO_DEVICE", -7: "SDFR_ERR_COMPILE", -8: "SDFR_ERR_COMM",
+    -4: "SDFR_ERR_NO_SCENE", -5: "SDFR_ERR_HIP", -6: "SDFR_ERR_NO_DEVICE", -7: "SDFR_ERR_COMPILE", -8: "SDFR_ERR_COMM", -9: "SDFR_ERR_INTERNAL",
 }
 
 
@@ -82,8 +81,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_close", "sdfr_comm_library_info", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
-    "sdfr_register_host_target", "sdfr_peer_region_create", "sdfr_peer_region_open", "sdfr_peer_region_close", "sdfr_peer_region_status",
-    "sdfr_render_gather_peer",
+    "sdfr_register_host_target",
 ]
 
 _lib = None
@@ -145,11 +143,6 @@ def load_library():
     L.sdfr_set_launch_mode.argtypes = [vp, ci]
     L.sdfr_set_step_shortcuts.argtypes = [vp, ci]
     L.sdfr_register_host_target.argtypes = [vp, vp, ctypes.c_size_t]
-    L.sdfr_peer_region_create.argtypes = [vp, ctypes.c_size_t, ci, vp]
-    L.sdfr_peer_region_open.argtypes = [vp, vp]
-    L.sdfr_peer_region_close.argtypes = [vp]
-    L.sdfr_peer_region_status.argtypes = [vp]
-    L.sdfr_render_gather_peer.argtypes = [vp, ci, ci, ci, ci, vp, ci, ci]
     L.sdfr_strip_buffer_pixels.argtypes = [ci, ci, ci]
     L.sdfr_strip_buffer_pixels.restype = ctypes.c_int64
     L.sdfr_strip_buffer_bytes.argtypes = [ci, ci, ci, ci]
@@ -506,35 +499,6 @@ class SDFRenderer:
             assert out.element_size() == (4 if fmt == RGBA32F else 2)
             ptr = ctypes.c_void_p(out.data_ptr())
         self._check(self._L.sdfr_render_gather(self._h, comm._c, width, height, ptr, fmt, wire))
-        return out
-
-    # ---- the gather without a collective library (sdfr_peer_region_*, sdfr_render_gather_peer; experimental)
-    def peerRegionCreate(self, capacity_bytes, world):
-        """rank 0: allocate and export the gathered buffer; returns the descriptor bytes to hand to the peers"""
-        buf = ctypes.create_string_buffer(PEER_REGION_BYTES)
-        self._check(self._L.sdfr_peer_region_create(self._h, int(capacity_bytes), int(world), buf))
-        return bytes(buf.raw)
-
-    def peerRegionOpen(self, descriptor):
-        assert len(descriptor) == PEER_REGION_BYTES
-        self._check(self._L.sdfr_peer_region_open(self._h, ctypes.c_char_p(descriptor)))
-
-    def peerRegionClose(self):
-        self._check(self._L.sdfr_peer_region_close(self._h))
-
-    def peerRegionStatus(self):
-        """waits for the handle's work; raises SdfrError(SDFR_ERR_COMM) if a wait of the peer-copy gather gave up"""
-        self._check(self._L.sdfr_peer_region_status(self._h))
-
-    def renderGatherPeer(self, rank, world, width, height, out=None, fmt=RGBA32F, wire=None):
-        if wire is None:
-            wire = STRIP_RGB32F_A8 if fmt == RGBA32F else STRIP_RGB16F_A8
-        ptr = None
-        if out is not None:
-            assert out.is_cuda and out.is_contiguous() and out.numel() == width * height * 4
-            assert out.element_size() == (4 if fmt == RGBA32F else 2)
-            ptr = ctypes.c_void_p(out.data_ptr())
-        self._check(self._L.sdfr_render_gather_peer(self._h, int(rank), int(world), width, height, ptr, fmt, wire))
         return out
 
     def getTimings(self):

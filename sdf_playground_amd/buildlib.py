@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdfr.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_hlsl.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_peer.hip", "sdfr_post.hip"]
+SOURCES = ["sdfr_api.cpp", "sdfr_comm.cpp", "sdfr_hlsl.cpp", "sdfr_jit.cpp", "sdfr_kernels.hip", "sdfr_post.hip"]
 GROUP_SOURCE = "sdfr_kernels_group.hip"
 ARCH = "gfx950"
 # Per scene: options that change the register ASSIGNMENT or the instruction ORDER of its kernels, never the arithmetic.  A three-source

@@ -107,48 +107,50 @@ extern "C" {
 
 int sdfr_create(int device_ordinal, sdfr_renderer **out)
 {
-	if (!out) return SDFR_ERR_INVALID_ARGUMENT;
-	*out = nullptr;
-	int count = 0;
-	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
-	if (device_ordinal < 0 || device_ordinal >= count) return SDFR_ERR_INVALID_ARGUMENT;
-	if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
-	sdfr_renderer *r = new sdfr_renderer();
-	r->device = device_ordinal;
-	if (const char *t = getenv("SDFR_TILE_W_LOG2")) // developer knob: wave tile shape (3 = 8x8 ... 6 = 64x1)
-	{
-		int v = atoi(t);
-		if (v >= 3 && v <= 6) r->tile_w_log2 = v;
-	}
-	if (const char *t = getenv("SDFR_STEP_SHORTCUTS")) r->step_shortcuts = atoi(t) != 0; // default of sdfr_set_step_shortcuts
-	frame_defaults(r->U);
-	// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
-	host::Camera cam;
-	cam.SetAspect(1200.f / 800.f);
-	cam.SetFOVY(60.f * 3.14159265358979f / 180.f);
-	cam.SetRoll(0.f);
-	cam.SetEye(host::Vec3(0.f, 2.f, -3.f));
-	cam.SetLookat(host::Vec3(0.f, 1.f, 0.f));
-	host::Vec3 e, f, rt, tp;
-	cam.GetBasis(e, f, rt, tp);
-	r->U.eye = V3(e.x, e.y, e.z);
-	r->U.front = V3(f.x, f.y, f.z);
-	r->U.right = V3(rt.x, rt.y, rt.z);
-	r->U.top = V3(tp.x, tp.y, tp.z);
-	if (hipMalloc((void **)&r->d_totals, 2 * sizeof(RenderTotals)) != hipSuccess || hipEventCreate(&r->ev_begin) != hipSuccess ||
-		hipEventCreate(&r->ev_end) != hipSuccess)
-	{
-		delete r;
-		return SDFR_ERR_HIP;
-	}
-	for (int i = 0; i < 32; ++i)
-	{
-		if (i < 3) (void)hipEventCreate(&r->ev_post[i]);
-		(void)hipEventCreate(&r->ev_march[i]);
-		(void)hipEventCreate(&r->ev_shade[i]);
-	}
-	*out = r;
-	return SDFR_OK;
+	return guarded(nullptr, [&]() -> int {
+		if (!out) return SDFR_ERR_INVALID_ARGUMENT;
+		*out = nullptr;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
+		if (device_ordinal < 0 || device_ordinal >= count) return SDFR_ERR_INVALID_ARGUMENT;
+		if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
+		sdfr_renderer *r = new sdfr_renderer();
+		r->device = device_ordinal;
+		if (const char *t = getenv("SDFR_TILE_W_LOG2")) // developer knob: wave tile shape (3 = 8x8 ... 6 = 64x1)
+		{
+			int v = atoi(t);
+			if (v >= 3 && v <= 6) r->tile_w_log2 = v;
+		}
+		if (const char *t = getenv("SDFR_STEP_SHORTCUTS")) r->step_shortcuts = atoi(t) != 0; // default of sdfr_set_step_shortcuts
+		frame_defaults(r->U);
+		// start-up camera of the reference (Application.cpp:214-224), aspect of its 1200x800 window
+		host::Camera cam;
+		cam.SetAspect(1200.f / 800.f);
+		cam.SetFOVY(60.f * 3.14159265358979f / 180.f);
+		cam.SetRoll(0.f);
+		cam.SetEye(host::Vec3(0.f, 2.f, -3.f));
+		cam.SetLookat(host::Vec3(0.f, 1.f, 0.f));
+		host::Vec3 e, f, rt, tp;
+		cam.GetBasis(e, f, rt, tp);
+		r->U.eye = V3(e.x, e.y, e.z);
+		r->U.front = V3(f.x, f.y, f.z);
+		r->U.right = V3(rt.x, rt.y, rt.z);
+		r->U.top = V3(tp.x, tp.y, tp.z);
+		if (hipMalloc((void **)&r->d_totals, 2 * sizeof(RenderTotals)) != hipSuccess || hipEventCreate(&r->ev_begin) != hipSuccess ||
+			hipEventCreate(&r->ev_end) != hipSuccess)
+		{
+			delete r;
+			return SDFR_ERR_HIP;
+		}
+		for (int i = 0; i < 32; ++i)
+		{
+			if (i < 3) (void)hipEventCreate(&r->ev_post[i]);
+			(void)hipEventCreate(&r->ev_march[i]);
+			(void)hipEventCreate(&r->ev_shade[i]);
+		}
+		*out = r;
+		return SDFR_OK;
+	});
 }
 
 void sdfr_destroy(sdfr_renderer *r)
@@ -166,9 +168,6 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipFree(r->d_wire);
 	(void)hipFree(r->d_post_flags);
 	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
-	(void)sdfr_peer_region_close(r);
-	if (r->peer_status) (void)hipHostFree(r->peer_status);
-	if (r->d_peer_gave_up) (void)hipFree(r->d_peer_gave_up);
 	if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
 	if (r->ev_strips) (void)hipEventDestroy(r->ev_strips);
 	if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
@@ -189,9 +188,11 @@ const char *sdfr_last_error(const sdfr_renderer *r) { return r ? r->error.c_str(
 
 int sdfr_set_stream(sdfr_renderer *r, void *hip_stream)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	r->stream = (hipStream_t)hip_stream;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		r->stream = (hipStream_t)hip_stream;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_scene_count(void) { return SDFR_PUBLIC_SCENE_COUNT; }
@@ -229,102 +230,114 @@ static int build_variable_table(sdfr_renderer *r, const std::string &scene_text,
 
 int sdfr_load_scene(sdfr_renderer *r, const char *name)
 {
-	if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
-	const int idx = scene_index(name);
-	if (idx < 0) return fail(r, SDFR_ERR_UNKNOWN_SCENE, std::string("unknown scene '") + name + "'");
-	host::ShaderVariableManager vm;
-	std::vector<std::string> slots;
-	const int rc = build_variable_table(r, scene_variables(idx), vm, slots);
-	if (rc != SDFR_OK) return rc;
-	r->vars = vm;
-	r->scene_var_slots = slots;
-	r->scene = idx;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
+		const int idx = scene_index(name);
+		if (idx < 0) return fail(r, SDFR_ERR_UNKNOWN_SCENE, std::string("unknown scene '") + name + "'");
+		host::ShaderVariableManager vm;
+		std::vector<std::string> slots;
+		const int rc = build_variable_table(r, scene_variables(idx), vm, slots);
+		if (rc != SDFR_OK) return rc;
+		r->vars = vm;
+		r->scene_var_slots = slots;
+		r->scene = idx;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_check_scene_source(const char *source, const char *arch, char *log, size_t log_bytes)
 {
-	if (!source) return SDFR_ERR_INVALID_ARGUMENT;
-	if (log && log_bytes) log[0] = 0;
-	sdfr_renderer scratch; // only its error string is used
-	host::ShaderVariableManager vm;
-	std::vector<std::string> slots;
-	std::string err;
-	int rc = build_variable_table(&scratch, source, vm, slots);
-	if (rc != SDFR_OK) err = scratch.error;
-	std::vector<char> code;
-	if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", source, slots, code, err)) rc = SDFR_ERR_COMPILE;
-	if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
-	return rc;
+	return guarded(nullptr, [&]() -> int {
+		if (!source) return SDFR_ERR_INVALID_ARGUMENT;
+		if (log && log_bytes) log[0] = 0;
+		sdfr_renderer scratch; // only its error string is used
+		host::ShaderVariableManager vm;
+		std::vector<std::string> slots;
+		std::string err;
+		int rc = build_variable_table(&scratch, source, vm, slots);
+		if (rc != SDFR_OK) err = scratch.error;
+		std::vector<char> code;
+		if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", source, slots, code, err)) rc = SDFR_ERR_COMPILE;
+		if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
+		return rc;
+	});
 }
 
 // ---- scenes in the reference's own dialect (sdfr_hlsl.h / sdfr_hlsl.cpp) ------------------------------------
 int sdfr_translate_scene_hlsl(const char *hlsl_source, char *out, size_t out_bytes)
 {
-	if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
-	const std::string text = hlsl_scene_source(hlsl_source);
-	if (out && out_bytes) snprintf(out, out_bytes, "%s", text.c_str());
-	return (int)text.size() + 1;
+	return guarded(nullptr, [&]() -> int {
+		if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+		const std::string text = hlsl_scene_source(hlsl_source);
+		if (out && out_bytes) snprintf(out, out_bytes, "%s", text.c_str());
+		return (int)text.size() + 1;
+	});
 }
 
 int sdfr_check_scene_hlsl(const char *hlsl_source, const char *arch, char *log, size_t log_bytes)
 {
-	if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
-	// the variable table comes from the tags of the ORIGINAL text (ShaderUtil.cpp:122-191); the generated class reads them
-	// through the same VAR_<name>(...) macros as any run-time scene
-	if (log && log_bytes) log[0] = 0;
-	sdfr_renderer scratch;
-	host::ShaderVariableManager vm;
-	std::vector<std::string> slots;
-	std::string err;
-	int rc = build_variable_table(&scratch, hlsl_source, vm, slots);
-	if (rc != SDFR_OK) err = scratch.error;
-	std::vector<char> code;
-	if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", hlsl_scene_source(hlsl_source), slots, code, err)) rc = SDFR_ERR_COMPILE;
-	if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
-	return rc;
+	return guarded(nullptr, [&]() -> int {
+		if (!hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+		// the variable table comes from the tags of the ORIGINAL text (ShaderUtil.cpp:122-191); the generated class reads them
+		// through the same VAR_<name>(...) macros as any run-time scene
+		if (log && log_bytes) log[0] = 0;
+		sdfr_renderer scratch;
+		host::ShaderVariableManager vm;
+		std::vector<std::string> slots;
+		std::string err;
+		int rc = build_variable_table(&scratch, hlsl_source, vm, slots);
+		if (rc != SDFR_OK) err = scratch.error;
+		std::vector<char> code;
+		if (rc == SDFR_OK && !jit_compile_code(arch && arch[0] ? arch : "gfx950", "scene", hlsl_scene_source(hlsl_source), slots, code, err)) rc = SDFR_ERR_COMPILE;
+		if (rc != SDFR_OK && log && log_bytes) snprintf(log, log_bytes, "%s", err.c_str());
+		return rc;
+	});
 }
 
 int sdfr_load_scene_hlsl(sdfr_renderer *r, const char *name, const char *hlsl_source)
 {
-	if (!r || !name || !hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
-	SDFR_HIP(hipSetDevice(r->device));
-	host::ShaderVariableManager vm;
-	std::vector<std::string> slots;
-	const int rc = build_variable_table(r, hlsl_source, vm, slots);
-	if (rc != SDFR_OK) return rc;
-	JitScene js;
-	std::string err;
-	if (!jit_compile(r->device, name, hlsl_scene_source(hlsl_source), slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
-	SDFR_HIP(hipStreamSynchronize(r->stream));
-	jit_unload(r->jit);
-	r->jit = js;
-	r->vars = vm;
-	r->scene_var_slots = slots;
-	r->scene = SDFR_SCENE_COUNT;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !name || !hlsl_source) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipSetDevice(r->device));
+		host::ShaderVariableManager vm;
+		std::vector<std::string> slots;
+		const int rc = build_variable_table(r, hlsl_source, vm, slots);
+		if (rc != SDFR_OK) return rc;
+		JitScene js;
+		std::string err;
+		if (!jit_compile(r->device, name, hlsl_scene_source(hlsl_source), slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		jit_unload(r->jit);
+		r->jit = js;
+		r->vars = vm;
+		r->scene_var_slots = slots;
+		r->scene = SDFR_SCENE_COUNT;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *source)
 {
-	if (!r || !name || !source) return SDFR_ERR_INVALID_ARGUMENT;
-	SDFR_HIP(hipSetDevice(r->device));
-	host::ShaderVariableManager vm;
-	std::vector<std::string> slots;
-	const int rc = build_variable_table(r, source, vm, slots);
-	if (rc != SDFR_OK) return rc;
-	JitScene js;
-	std::string err;
-	// like the reference, a scene that fails to compile leaves the previous one in place
-	// (SceneManager.cpp:118-127 keeps the old shader and shows the compiler's message)
-	if (!jit_compile(r->device, name, source, slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
-	SDFR_HIP(hipStreamSynchronize(r->stream));
-	jit_unload(r->jit);
-	r->jit = js;
-	r->vars = vm;
-	r->scene_var_slots = slots;
-	r->scene = SDFR_SCENE_COUNT;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !name || !source) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipSetDevice(r->device));
+		host::ShaderVariableManager vm;
+		std::vector<std::string> slots;
+		const int rc = build_variable_table(r, source, vm, slots);
+		if (rc != SDFR_OK) return rc;
+		JitScene js;
+		std::string err;
+		// like the reference, a scene that fails to compile leaves the previous one in place
+		// (SceneManager.cpp:118-127 keeps the old shader and shows the compiler's message)
+		if (!jit_compile(r->device, name, source, slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		jit_unload(r->jit);
+		r->jit = js;
+		r->vars = vm;
+		r->scene_var_slots = slots;
+		r->scene = SDFR_SCENE_COUNT;
+		return SDFR_OK;
+	});
 }
 
 const char *sdfr_current_scene(const sdfr_renderer *r)
@@ -337,53 +350,63 @@ int sdfr_var_count(const sdfr_renderer *r) { return r ? (int)r->vars.getVariable
 
 int sdfr_var_info(const sdfr_renderer *r, int index, sdfr_variable *out)
 {
-	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	const auto &m = r->vars.getVariables();
-	if (index < 0 || index >= (int)m.size()) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "variable index out of range");
-	auto it = m.begin();
-	std::advance(it, index);
-	memset(out, 0, sizeof *out);
-	snprintf(out->name, sizeof out->name, "%s", it->first.c_str());
-	out->minval = it->second.minval;
-	out->maxval = it->second.maxval;
-	out->start = it->second.start;
-	out->step = it->second.step;
-	out->value = it->second.value;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+		const auto &m = r->vars.getVariables();
+		if (index < 0 || index >= (int)m.size()) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "variable index out of range");
+		auto it = m.begin();
+		std::advance(it, index);
+		memset(out, 0, sizeof *out);
+		snprintf(out->name, sizeof out->name, "%s", it->first.c_str());
+		out->minval = it->second.minval;
+		out->maxval = it->second.maxval;
+		out->start = it->second.start;
+		out->step = it->second.step;
+		out->value = it->second.value;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_var_set(sdfr_renderer *r, const char *name, float value)
 {
-	if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
-	if (!r->vars.setValue(name, value)) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "' (ignored)");
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !name) return SDFR_ERR_INVALID_ARGUMENT;
+		if (!r->vars.setValue(name, value)) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "' (ignored)");
+		return SDFR_OK;
+	});
 }
 
 int sdfr_var_get(const sdfr_renderer *r, const char *name, float *out)
 {
-	if (!r || !name || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	const auto &m = r->vars.getVariables();
-	auto it = m.find(std::string_view(name));
-	if (it == m.end()) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "'");
-	*out = it->second.value;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !name || !out) return SDFR_ERR_INVALID_ARGUMENT;
+		const auto &m = r->vars.getVariables();
+		auto it = m.find(std::string_view(name));
+		if (it == m.end()) return fail(r, SDFR_ERR_UNKNOWN_VARIABLE, std::string("unknown variable '") + name + "'");
+		*out = it->second.value;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_vars_reset(sdfr_renderer *r)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	for (auto &kv : r->vars.getVariables()) kv.second.value = kv.second.start;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		for (auto &kv : r->vars.getVariables()) kv.second.value = kv.second.start;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_camera(sdfr_renderer *r, const float eye[3], const float front[3], const float right[3], const float top[3])
 {
-	if (!r || !eye || !front || !right || !top) return SDFR_ERR_INVALID_ARGUMENT;
-	r->U.eye = V3(eye[0], eye[1], eye[2]);
-	r->U.front = V3(front[0], front[1], front[2]);
-	r->U.right = V3(right[0], right[1], right[2]);
-	r->U.top = V3(top[0], top[1], top[2]);
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !eye || !front || !right || !top) return SDFR_ERR_INVALID_ARGUMENT;
+		r->U.eye = V3(eye[0], eye[1], eye[2]);
+		r->U.front = V3(front[0], front[1], front[2]);
+		r->U.right = V3(right[0], right[1], right[2]);
+		r->U.top = V3(top[0], top[1], top[2]);
+		return SDFR_OK;
+	});
 }
 
 static int set_camera_from(sdfr_renderer *r, const host::Camera &cam)
@@ -399,120 +422,140 @@ static int set_camera_from(sdfr_renderer *r, const host::Camera &cam)
 
 int sdfr_set_camera_lookat(sdfr_renderer *r, const float eye[3], const float lookat[3], float fovy, float aspect, float roll)
 {
-	if (!r || !eye || !lookat) return SDFR_ERR_INVALID_ARGUMENT;
-	host::Camera cam;
-	cam.SetAspect(aspect);
-	cam.SetFOVY(fovy);
-	cam.SetRoll(roll);
-	cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
-	cam.SetLookat(host::Vec3(lookat[0], lookat[1], lookat[2]));
-	return set_camera_from(r, cam);
+	return guarded(r, [&]() -> int {
+		if (!r || !eye || !lookat) return SDFR_ERR_INVALID_ARGUMENT;
+		host::Camera cam;
+		cam.SetAspect(aspect);
+		cam.SetFOVY(fovy);
+		cam.SetRoll(roll);
+		cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
+		cam.SetLookat(host::Vec3(lookat[0], lookat[1], lookat[2]));
+		return set_camera_from(r, cam);
+	});
 }
 
 int sdfr_set_camera_direction(sdfr_renderer *r, const float eye[3], const float direction[3], float fovy, float aspect, float roll)
 {
-	if (!r || !eye || !direction) return SDFR_ERR_INVALID_ARGUMENT;
-	host::Camera cam;
-	cam.SetAspect(aspect);
-	cam.SetFOVY(fovy);
-	cam.SetRoll(roll);
-	cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
-	cam.SetDirection(host::Vec3(direction[0], direction[1], direction[2]));
-	return set_camera_from(r, cam);
+	return guarded(r, [&]() -> int {
+		if (!r || !eye || !direction) return SDFR_ERR_INVALID_ARGUMENT;
+		host::Camera cam;
+		cam.SetAspect(aspect);
+		cam.SetFOVY(fovy);
+		cam.SetRoll(roll);
+		cam.SetEye(host::Vec3(eye[0], eye[1], eye[2]));
+		cam.SetDirection(host::Vec3(direction[0], direction[1], direction[2]));
+		return set_camera_from(r, cam);
+	});
 }
 
 int sdfr_get_camera(const sdfr_renderer *r, float out[12])
 {
-	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	const vec3 v[4] = {r->U.eye, r->U.front, r->U.right, r->U.top};
-	for (int i = 0; i < 4; ++i)
-	{
-		out[3 * i + 0] = v[i].x;
-		out[3 * i + 1] = v[i].y;
-		out[3 * i + 2] = v[i].z;
-	}
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+		const vec3 v[4] = {r->U.eye, r->U.front, r->U.right, r->U.top};
+		for (int i = 0; i < 4; ++i)
+		{
+			out[3 * i + 0] = v[i].x;
+			out[3 * i + 1] = v[i].y;
+			out[3 * i + 2] = v[i].z;
+		}
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_time(sdfr_renderer *r, float stime)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	r->U.stime = stime;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		r->U.stime = stime;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_get_limits(const sdfr_renderer *r, sdfr_limits *out)
 {
-	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	out->iter_count = r->U.iter_count;
-	out->bounce_count = r->U.bounce_count;
-	out->ray_count = r->U.ray_count;
-	out->light_count = r->U.light_count;
-	out->range = r->U.range;
-	out->max_cost_default = (int)r->U.max_cost_default;
-	out->extension_lights = r->U.extension_lights;
-	out->extension_marble_reflection = r->U.extension_marble_reflection;
-	out->dist_eps = r->U.dist_eps;
-	out->grad_eps = r->U.grad_eps;
-	out->reflect_eps = r->U.reflect_eps;
-	out->refract_eps = r->U.refract_eps;
-	out->shadow_eps = r->U.shadow_eps;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+		out->iter_count = r->U.iter_count;
+		out->bounce_count = r->U.bounce_count;
+		out->ray_count = r->U.ray_count;
+		out->light_count = r->U.light_count;
+		out->range = r->U.range;
+		out->max_cost_default = (int)r->U.max_cost_default;
+		out->extension_lights = r->U.extension_lights;
+		out->extension_marble_reflection = r->U.extension_marble_reflection;
+		out->dist_eps = r->U.dist_eps;
+		out->grad_eps = r->U.grad_eps;
+		out->reflect_eps = r->U.reflect_eps;
+		out->refract_eps = r->U.refract_eps;
+		out->shadow_eps = r->U.shadow_eps;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_limits(sdfr_renderer *r, const sdfr_limits *l)
 {
-	if (!r || !l) return SDFR_ERR_INVALID_ARGUMENT;
-	if (l->iter_count < 1 || l->iter_count > 0xffffff || l->bounce_count < 0 || l->bounce_count > 16 || l->ray_count < 1 ||
-		l->ray_count > SDFR_MAX_RAYS || l->light_count < 0 || l->light_count > SDFR_MAX_LIGHTS || l->max_cost_default < 0 ||
-		l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1 ||
-		!(l->extension_marble_reflection >= 0.f && l->extension_marble_reflection <= 1.f))
-		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
-	if (!(l->dist_eps > 0.f && l->dist_eps <= SDFR_MAX_DIST_EPS) || !(l->grad_eps > 0.f && l->grad_eps <= 1.f) || !(l->reflect_eps >= 0.f && l->reflect_eps <= 1.f) ||
-		!(l->refract_eps >= 0.f && l->refract_eps <= 1.f) || !(l->shadow_eps >= 0.f && l->shadow_eps <= 1.f))
-		return fail(r, SDFR_ERR_INVALID_ARGUMENT, "epsilons out of range (0 < dist_eps <= 1e-3, 0 < grad_eps <= 1, 0 <= reflect_eps, refract_eps, shadow_eps <= 1)");
-	r->U.iter_count = l->iter_count;
-	r->U.bounce_count = l->bounce_count;
-	r->U.ray_count = l->ray_count;
-	r->U.light_count = l->light_count;
-	r->U.range = l->range;
-	r->U.max_cost_default = (uint32_t)l->max_cost_default;
-	r->U.extension_lights = l->extension_lights;
-	r->U.extension_marble_reflection = l->extension_marble_reflection;
-	r->U.dist_eps = l->dist_eps;
-	r->U.grad_eps = l->grad_eps;
-	r->U.reflect_eps = l->reflect_eps;
-	r->U.refract_eps = l->refract_eps;
-	r->U.shadow_eps = l->shadow_eps;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !l) return SDFR_ERR_INVALID_ARGUMENT;
+		if (l->iter_count < 1 || l->iter_count > 0xffffff || l->bounce_count < 0 || l->bounce_count > 16 || l->ray_count < 1 ||
+			l->ray_count > SDFR_MAX_RAYS || l->light_count < 0 || l->light_count > SDFR_MAX_LIGHTS || l->max_cost_default < 0 ||
+			l->max_cost_default > 250 || !(l->range == l->range) || l->extension_lights < 0 || l->extension_lights > SDFR_MAX_LIGHTS - 1 ||
+			!(l->extension_marble_reflection >= 0.f && l->extension_marble_reflection <= 1.f))
+			return fail(r, SDFR_ERR_INVALID_ARGUMENT, "limits out of range");
+		if (!(l->dist_eps > 0.f && l->dist_eps <= SDFR_MAX_DIST_EPS) || !(l->grad_eps > 0.f && l->grad_eps <= 1.f) || !(l->reflect_eps >= 0.f && l->reflect_eps <= 1.f) ||
+			!(l->refract_eps >= 0.f && l->refract_eps <= 1.f) || !(l->shadow_eps >= 0.f && l->shadow_eps <= 1.f))
+			return fail(r, SDFR_ERR_INVALID_ARGUMENT, "epsilons out of range (0 < dist_eps <= 1e-3, 0 < grad_eps <= 1, 0 <= reflect_eps, refract_eps, shadow_eps <= 1)");
+		r->U.iter_count = l->iter_count;
+		r->U.bounce_count = l->bounce_count;
+		r->U.ray_count = l->ray_count;
+		r->U.light_count = l->light_count;
+		r->U.range = l->range;
+		r->U.max_cost_default = (uint32_t)l->max_cost_default;
+		r->U.extension_lights = l->extension_lights;
+		r->U.extension_marble_reflection = l->extension_marble_reflection;
+		r->U.dist_eps = l->dist_eps;
+		r->U.grad_eps = l->grad_eps;
+		r->U.reflect_eps = l->reflect_eps;
+		r->U.refract_eps = l->refract_eps;
+		r->U.shadow_eps = l->shadow_eps;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_profiling(sdfr_renderer *r, int enabled)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	r->profiling = enabled != 0;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		r->profiling = enabled != 0;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_launch_mode(sdfr_renderer *r, int mode)
 {
-	if (!r || mode < SDFR_LAUNCH_AUTO || mode > SDFR_LAUNCH_PERSISTENT) return SDFR_ERR_INVALID_ARGUMENT;
-	r->launch_mode = mode;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || mode < SDFR_LAUNCH_AUTO || mode > SDFR_LAUNCH_PERSISTENT) return SDFR_ERR_INVALID_ARGUMENT;
+		r->launch_mode = mode;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_step_shortcuts(sdfr_renderer *r, int enabled)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	r->step_shortcuts = enabled != 0;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		r->step_shortcuts = enabled != 0;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_set_schedule(sdfr_renderer *r, int schedule)
 {
-	if (!r || (schedule != SDFR_SCHEDULE_WAVEFRONT && schedule != SDFR_SCHEDULE_PIXEL)) return SDFR_ERR_INVALID_ARGUMENT;
-	r->schedule = schedule;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || (schedule != SDFR_SCHEDULE_WAVEFRONT && schedule != SDFR_SCHEDULE_PIXEL)) return SDFR_ERR_INVALID_ARGUMENT;
+		r->schedule = schedule;
+		return SDFR_OK;
+	});
 }
 
 int64_t sdfr_strip_buffer_bytes(int width, int height, int world, int format) { return sdfr_strip_buffer_bytes_split(width, height, world, format, 0, 1); }
@@ -539,10 +582,12 @@ int64_t sdfr_strip_buffer_pixels_split(int width, int height, int world, int pri
 
 int sdfr_set_strip_split(sdfr_renderer *r, int priv_count, int priv_period)
 {
-	if (!r || priv_count < 0 || priv_period < 1 || priv_count >= priv_period || priv_period > 4096) return SDFR_ERR_INVALID_ARGUMENT;
-	r->priv_count = priv_count;
-	r->priv_period = priv_period;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || priv_count < 0 || priv_period < 1 || priv_count >= priv_period || priv_period > 4096) return SDFR_ERR_INVALID_ARGUMENT;
+		r->priv_count = priv_count;
+		r->priv_period = priv_period;
+		return SDFR_OK;
+	});
 }
 
 // latch the variable values into the frame uniforms (the reference uploads them every frame,
@@ -696,194 +741,216 @@ extern "C" {
 
 int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
 {
-	return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, RENDER_FULL);
+	return guarded(r, [&]() -> int {
+		return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, RENDER_FULL);
+	});
 }
 
 int sdfr_render_strips(sdfr_renderer *r, int width, int height, int rank, int world, void *out_compact, int format)
 {
-	return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr, RENDER_STRIPS);
+	return guarded(r, [&]() -> int {
+		return render_impl(r, width, height, rank, world, out_compact, format, 0, nullptr, RENDER_STRIPS);
+	});
 }
 
 int sdfr_render_private_strips(sdfr_renderer *r, int width, int height, void *out_image, int format)
 {
-	return render_impl(r, width, height, 0, 1, out_image, format, 0, nullptr, RENDER_PRIVATE);
+	return guarded(r, [&]() -> int {
+		return render_impl(r, width, height, 0, 1, out_image, format, 0, nullptr, RENDER_PRIVATE);
+	});
 }
 
 int sdfr_assemble_strips(sdfr_renderer *r, int width, int height, int world, const void *gathered, void *out_image, int format)
 {
-	if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
-	if (!is_wire_format(format)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
-	SDFR_HIP(hipSetDevice(r->device));
-	hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->priv_count, r->priv_period, r->stream);
-	if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !gathered || !out_image || width < 1 || height < 1 || world < 1) return SDFR_ERR_INVALID_ARGUMENT;
+		if (!is_wire_format(format)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad format");
+		SDFR_HIP(hipSetDevice(r->device));
+		hipError_t e = launch_assemble_strips(width, height, world, gathered, out_image, format, r->priv_count, r->priv_period, r->stream);
+		if (e != hipSuccess) return hip_fail(r, e, "assemble launch");
+		return SDFR_OK;
+	});
 }
 
 int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_rgba16f, void *bloom_scratch_rgba16f, void *out_rgba8)
 {
-	if (!r || !scene_rgba16f || !bloom_scratch_rgba16f || !out_rgba8) return SDFR_ERR_INVALID_ARGUMENT;
-	if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
-	SDFR_HIP(hipSetDevice(r->device));
-	const size_t flag_bytes = postprocess_flag_bytes(width, height);
-	if (r->post_flag_bytes < flag_bytes)
-	{
-		SDFR_HIP(hipStreamSynchronize(r->stream)); // a postprocess still in flight reads the old one
-		(void)hipFree(r->d_post_flags);
-		r->d_post_flags = nullptr;
-		r->post_flag_bytes = 0;
-		SDFR_HIP(hipMalloc((void **)&r->d_post_flags, flag_bytes));
-		r->post_flag_bytes = flag_bytes;
-	}
-	SDFR_HIP(hipEventRecord(r->ev_post[0], r->stream));
-	hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->d_post_flags, r->stream, r->ev_post[1]);
-	if (e != hipSuccess) return hip_fail(r, e, "postprocess launch");
-	SDFR_HIP(hipEventRecord(r->ev_post[2], r->stream));
-	r->have_post = true;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !scene_rgba16f || !bloom_scratch_rgba16f || !out_rgba8) return SDFR_ERR_INVALID_ARGUMENT;
+		if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad frame size");
+		SDFR_HIP(hipSetDevice(r->device));
+		const size_t flag_bytes = postprocess_flag_bytes(width, height);
+		if (r->post_flag_bytes < flag_bytes)
+		{
+			SDFR_HIP(hipStreamSynchronize(r->stream)); // a postprocess still in flight reads the old one
+			(void)hipFree(r->d_post_flags);
+			r->d_post_flags = nullptr;
+			r->post_flag_bytes = 0;
+			SDFR_HIP(hipMalloc((void **)&r->d_post_flags, flag_bytes));
+			r->post_flag_bytes = flag_bytes;
+		}
+		SDFR_HIP(hipEventRecord(r->ev_post[0], r->stream));
+		hipError_t e = launch_postprocess(width, height, scene_rgba16f, bloom_scratch_rgba16f, out_rgba8, r->d_post_flags, r->stream, r->ev_post[1]);
+		if (e != hipSuccess) return hip_fail(r, e, "postprocess launch");
+		SDFR_HIP(hipEventRecord(r->ev_post[2], r->stream));
+		r->have_post = true;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches)
 {
-	if (!r || !mismatches || what < 0 || what > 5) return SDFR_ERR_INVALID_ARGUMENT;
-	if (what >= 1 && !(constant != 0.f && constant == constant)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad divisor");
-	SDFR_HIP(hipSetDevice(r->device));
-	unsigned long long *d = nullptr;
-	SDFR_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
-	hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), r->stream);
-	if (e == hipSuccess) e = launch_selftest_math(what, constant, d, r->stream);
-	unsigned long long h = 0;
-	if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, r->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
-	(void)hipFree(d);
-	if (e != hipSuccess) return hip_fail(r, e, "selftest");
-	*mismatches = h;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !mismatches || what < 0 || what > 5) return SDFR_ERR_INVALID_ARGUMENT;
+		if (what >= 1 && !(constant != 0.f && constant == constant)) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "bad divisor");
+		SDFR_HIP(hipSetDevice(r->device));
+		unsigned long long *d = nullptr;
+		SDFR_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+		hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), r->stream);
+		if (e == hipSuccess) e = launch_selftest_math(what, constant, d, r->stream);
+		unsigned long long h = 0;
+		if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, r->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+		(void)hipFree(d);
+		if (e != hipSuccess) return hip_fail(r, e, "selftest");
+		*mismatches = h;
+		return SDFR_OK;
+	});
 }
 
 #ifdef SDFR_WAVE_TRACE
 // developer build only (tools/wave_trace.py): the per-block records of the last pixel-schedule launch
 int sdfr_debug_read_partials(sdfr_renderer *r, void *host, size_t records)
 {
-	if (!r || !host) return SDFR_ERR_INVALID_ARGUMENT;
-	SDFR_HIP(hipStreamSynchronize(r->stream));
-	if (records > r->ws.capacity / 64 + 1) records = r->ws.capacity / 64 + 1;
-	SDFR_HIP(hipMemcpy(host, r->ws.partials, records * sizeof(RenderTotals), hipMemcpyDeviceToHost));
-	SDFR_HIP(hipMemset(r->ws.partials, 0, records * sizeof(RenderTotals))); // records the next launch does not write read as empty
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || !host) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		if (records > r->ws.capacity / 64 + 1) records = r->ws.capacity / 64 + 1;
+		SDFR_HIP(hipMemcpy(host, r->ws.partials, records * sizeof(RenderTotals), hipMemcpyDeviceToHost));
+		SDFR_HIP(hipMemset(r->ws.partials, 0, records * sizeof(RenderTotals))); // records the next launch does not write read as empty
+		return SDFR_OK;
+	});
 }
 #endif
 
 int sdfr_register_host_target(sdfr_renderer *r, void *host_image, size_t bytes)
 {
-	if (!r || (host_image && bytes == 0)) return SDFR_ERR_INVALID_ARGUMENT;
-	SDFR_HIP(hipSetDevice(r->device));
-	SDFR_HIP(hipStreamSynchronize(r->stream));
-	if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
-	r->pinned_host = nullptr;
-	r->pinned_bytes = 0;
-	if (!host_image) return SDFR_OK;
-	SDFR_HIP(hipHostRegister(host_image, bytes, hipHostRegisterDefault));
-	r->pinned_host = host_image;
-	r->pinned_bytes = bytes;
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r || (host_image && bytes == 0)) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipSetDevice(r->device));
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		if (r->pinned_host) (void)hipHostUnregister(r->pinned_host);
+		r->pinned_host = nullptr;
+		r->pinned_bytes = 0;
+		if (!host_image) return SDFR_OK;
+		SDFR_HIP(hipHostRegister(host_image, bytes, hipHostRegisterDefault));
+		r->pinned_host = host_image;
+		r->pinned_bytes = bytes;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_sync(sdfr_renderer *r)
 {
-	if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-	SDFR_HIP(hipStreamSynchronize(r->stream));
-	return SDFR_OK;
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		return SDFR_OK;
+	});
 }
 
 int sdfr_get_stats(sdfr_renderer *r, sdfr_stats *out)
 {
-	if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
-	memset(out, 0, sizeof *out);
-	if (!r->have_render) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "nothing rendered yet");
-	SDFR_HIP(hipEventSynchronize(r->ev_end));
-	float ms = 0.f;
-	SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
-	out->ms_gpu = ms;
-	RenderTotals t[2];
-	SDFR_HIP(hipMemcpy(t, r->d_totals, sizeof t, hipMemcpyDeviceToHost));
-	for (int k = 0; k < r->totals_parts; ++k)
-	{
-		out->pixels += t[k].pixels;
-		out->rays += t[k].rays;
-		out->march_evals += t[k].march_evals;
-		out->hits += t[k].hits;
-	}
-	if (r->last_wavefront)
-	{
-		for (int i = 0; r->last_profiled && i < r->last_rounds && i < 16; ++i)
+	return guarded(r, [&]() -> int {
+		if (!r || !out) return SDFR_ERR_INVALID_ARGUMENT;
+		memset(out, 0, sizeof *out);
+		if (!r->have_render) return fail(r, SDFR_ERR_INVALID_ARGUMENT, "nothing rendered yet");
+		SDFR_HIP(hipEventSynchronize(r->ev_end));
+		float ms = 0.f;
+		SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
+		out->ms_gpu = ms;
+		RenderTotals t[2];
+		SDFR_HIP(hipMemcpy(t, r->d_totals, sizeof t, hipMemcpyDeviceToHost));
+		for (int k = 0; k < r->totals_parts; ++k)
 		{
-			float a = 0.f, b = 0.f;
-			if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) == hipSuccess) out->ms_march += a;
-			if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) == hipSuccess) out->ms_shade += b;
+			out->pixels += t[k].pixels;
+			out->rays += t[k].rays;
+			out->march_evals += t[k].march_evals;
+			out->hits += t[k].hits;
 		}
-		out->march_launches = (uint32_t)r->last_rounds;
-		out->shade_launches = (uint32_t)r->last_rounds;
-	}
-	else
-	{
-		out->march_launches = 1;
-	}
-	return SDFR_OK;
+		if (r->last_wavefront)
+		{
+			for (int i = 0; r->last_profiled && i < r->last_rounds && i < 16; ++i)
+			{
+				float a = 0.f, b = 0.f;
+				if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) == hipSuccess) out->ms_march += a;
+				if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) == hipSuccess) out->ms_shade += b;
+			}
+			out->march_launches = (uint32_t)r->last_rounds;
+			out->shade_launches = (uint32_t)r->last_rounds;
+		}
+		else
+		{
+			out->march_launches = 1;
+		}
+		return SDFR_OK;
+	});
 }
 
 int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity)
 {
-	if (!r || (!out && capacity > 0) || capacity < 0) return SDFR_ERR_INVALID_ARGUMENT;
-	int n = 0;
-	auto put = [&](const char *name, double ms) {
-		if (n < capacity)
+	return guarded(r, [&]() -> int {
+		if (!r || (!out && capacity > 0) || capacity < 0) return SDFR_ERR_INVALID_ARGUMENT;
+		int n = 0;
+		auto put = [&](const char *name, double ms) {
+			if (n < capacity)
+			{
+				memset(&out[n], 0, sizeof out[n]);
+				snprintf(out[n].name, sizeof out[n].name, "%s", name);
+				out[n].ms = ms;
+			}
+			++n;
+		};
+		if (r->have_render)
 		{
-			memset(&out[n], 0, sizeof out[n]);
-			snprintf(out[n].name, sizeof out[n].name, "%s", name);
-			out[n].ms = ms;
+			SDFR_HIP(hipEventSynchronize(r->ev_end));
+			float ms = 0.f;
+			SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
+			put("setup", r->ms_setup);
+			put("draw", ms);
+			for (int i = 0; r->last_wavefront && r->last_profiled && i < r->last_rounds && i < 16; ++i)
+			{
+				float a = 0.f, b = 0.f;
+				char nm[32];
+				if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) != hipSuccess) continue;
+				if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) != hipSuccess) continue;
+				snprintf(nm, sizeof nm, "draw: march %d", i);
+				put(nm, a);
+				snprintf(nm, sizeof nm, "draw: shade %d", i);
+				put(nm, b);
+			}
 		}
-		++n;
-	};
-	if (r->have_render)
-	{
-		SDFR_HIP(hipEventSynchronize(r->ev_end));
-		float ms = 0.f;
-		SDFR_HIP(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end));
-		put("setup", r->ms_setup);
-		put("draw", ms);
-		for (int i = 0; r->last_wavefront && r->last_profiled && i < r->last_rounds && i < 16; ++i)
+		if (r->have_render && r->have_xfer)
 		{
-			float a = 0.f, b = 0.f;
+			// the last sdfr_render_gather's transfer on the comm stream: rank 0 receives world - 1 messages at once (one per link),
+			// a peer sends one; the bytes ride in the name so that a caller can turn the time into a rate
+			SDFR_HIP(hipEventSynchronize(r->ev_xfer[1]));
+			float t = 0.f;
+			SDFR_HIP(hipEventElapsedTime(&t, r->ev_xfer[0], r->ev_xfer[1]));
 			char nm[32];
-			if (hipEventElapsedTime(&a, r->ev_march[2 * i], r->ev_march[2 * i + 1]) != hipSuccess) continue;
-			if (hipEventElapsedTime(&b, r->ev_shade[2 * i], r->ev_shade[2 * i + 1]) != hipSuccess) continue;
-			snprintf(nm, sizeof nm, "draw: march %d", i);
-			put(nm, a);
-			snprintf(nm, sizeof nm, "draw: shade %d", i);
-			put(nm, b);
+			snprintf(nm, sizeof nm, "gather transfer %zu B", r->xfer_bytes);
+			put(nm, t);
 		}
-	}
-	if (r->have_render && r->have_xfer)
-	{
-		// the last sdfr_render_gather's transfer on the comm stream: rank 0 receives world - 1 messages at once (one per link),
-		// a peer sends one; the bytes ride in the name so that a caller can turn the time into a rate
-		SDFR_HIP(hipEventSynchronize(r->ev_xfer[1]));
-		float t = 0.f;
-		SDFR_HIP(hipEventElapsedTime(&t, r->ev_xfer[0], r->ev_xfer[1]));
-		char nm[32];
-		snprintf(nm, sizeof nm, "gather transfer %zu B", r->xfer_bytes);
-		put(nm, t);
-	}
-	if (r->have_post)
-	{
-		SDFR_HIP(hipEventSynchronize(r->ev_post[2]));
-		float a = 0.f, b = 0.f;
-		SDFR_HIP(hipEventElapsedTime(&a, r->ev_post[0], r->ev_post[1]));
-		SDFR_HIP(hipEventElapsedTime(&b, r->ev_post[1], r->ev_post[2]));
-		put("Bloom 1", a);
-		put("Bloom 2 + HDR", b); // the vertical blur and the tone map are one kernel here
-	}
-	return n;
+		if (r->have_post)
+		{
+			SDFR_HIP(hipEventSynchronize(r->ev_post[2]));
+			float a = 0.f, b = 0.f;
+			SDFR_HIP(hipEventElapsedTime(&a, r->ev_post[0], r->ev_post[1]));
+			SDFR_HIP(hipEventElapsedTime(&b, r->ev_post[1], r->ev_post[2]));
+			put("Bloom 1", a);
+			put("Bloom 2 + HDR", b); // the vertical blur and the tone map are one kernel here
+		}
+		return n;
+	});
 }
 
 } // extern "C"

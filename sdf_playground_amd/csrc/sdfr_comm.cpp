@@ -306,66 +306,72 @@ extern "C" {
 
 int sdfr_comm_unique_id(void *id_out)
 {
-	if (!id_out) return SDFR_ERR_INVALID_ARGUMENT;
-	int rc = need_rccl(nullptr);
-	if (rc != SDFR_OK) return rc;
-	static_assert(sizeof(ncclUniqueId) == SDFR_COMM_ID_BYTES, "SDFR_COMM_ID_BYTES");
-	ncclUniqueId id;
-	SDFR_NCCL(nullptr, rccl().get_unique_id(&id));
-	memcpy(id_out, &id, sizeof id);
-	return SDFR_OK;
+	return guarded(nullptr, [&]() -> int {
+		if (!id_out) return SDFR_ERR_INVALID_ARGUMENT;
+		int rc = need_rccl(nullptr);
+		if (rc != SDFR_OK) return rc;
+		static_assert(sizeof(ncclUniqueId) == SDFR_COMM_ID_BYTES, "SDFR_COMM_ID_BYTES");
+		ncclUniqueId id;
+		SDFR_NCCL(nullptr, rccl().get_unique_id(&id));
+		memcpy(id_out, &id, sizeof id);
+		return SDFR_OK;
+	});
 }
 
 int sdfr_comm_create(const void *id, int rank, int world, int device_ordinal, sdfr_comm **out)
 {
-	if (!out) return SDFR_ERR_INVALID_ARGUMENT;
-	*out = nullptr;
-	if (!id || world < 1 || rank < 0 || rank >= world) return SDFR_ERR_INVALID_ARGUMENT;
-	int count = 0;
-	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
-	if (device_ordinal < 0 || device_ordinal >= count) return SDFR_ERR_INVALID_ARGUMENT;
-	int rc = need_rccl(nullptr);
-	if (rc != SDFR_OK) return rc;
-	if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
-	ncclUniqueId uid;
-	memcpy(&uid, id, sizeof uid);
-	sdfr_comm *c = new sdfr_comm();
-	c->rank = rank;
-	c->world = world;
-	c->device = device_ordinal;
-	const ncclResult_t nrc = rccl().comm_init_rank(&c->comm, world, uid, rank);
-	if (nrc != ncclSuccess)
-	{
-		nccl_fail(nullptr, nrc, "ncclCommInitRank");
-		delete c;
-		return SDFR_ERR_COMM;
-	}
-	*out = c;
-	return SDFR_OK;
+	return guarded(nullptr, [&]() -> int {
+		if (!out) return SDFR_ERR_INVALID_ARGUMENT;
+		*out = nullptr;
+		if (!id || world < 1 || rank < 0 || rank >= world) return SDFR_ERR_INVALID_ARGUMENT;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
+		if (device_ordinal < 0 || device_ordinal >= count) return SDFR_ERR_INVALID_ARGUMENT;
+		int rc = need_rccl(nullptr);
+		if (rc != SDFR_OK) return rc;
+		if (hipSetDevice(device_ordinal) != hipSuccess) return SDFR_ERR_HIP;
+		ncclUniqueId uid;
+		memcpy(&uid, id, sizeof uid);
+		sdfr_comm *c = new sdfr_comm();
+		c->rank = rank;
+		c->world = world;
+		c->device = device_ordinal;
+		const ncclResult_t nrc = rccl().comm_init_rank(&c->comm, world, uid, rank);
+		if (nrc != ncclSuccess)
+		{
+			nccl_fail(nullptr, nrc, "ncclCommInitRank");
+			delete c;
+			return SDFR_ERR_COMM;
+		}
+		*out = c;
+		return SDFR_OK;
+	});
 }
 
 int sdfr_comm_create_all(const int *device_ordinals, int n, sdfr_comm **out_n)
 {
-	if (!device_ordinals || !out_n || n < 1 || n > 64) return SDFR_ERR_INVALID_ARGUMENT;
-	for (int i = 0; i < n; ++i) out_n[i] = nullptr;
-	int count = 0;
-	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
-	for (int i = 0; i < n; ++i)
-		if (device_ordinals[i] < 0 || device_ordinals[i] >= count) return SDFR_ERR_INVALID_ARGUMENT;
-	int rc = need_rccl(nullptr);
-	if (rc != SDFR_OK) return rc;
-	std::vector<ncclComm_t> comms((size_t)n, nullptr);
-	SDFR_NCCL(nullptr, rccl().comm_init_all(comms.data(), n, device_ordinals));
-	for (int i = 0; i < n; ++i)
-	{
-		sdfr_comm *c = new sdfr_comm();
-		c->comm = comms[(size_t)i];
-		c->rank = i;
-		c->world = n;
-		c->device = device_ordinals[i];
-		out_n[i] = c;
-	}
-	return SDFR_OK;
+	return guarded(nullptr, [&]() -> int {
+		if (!device_ordinals || !out_n || n < 1 || n > 64) return SDFR_ERR_INVALID_ARGUMENT;
+		for (int i = 0; i < n; ++i) out_n[i] = nullptr;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDFR_ERR_NO_DEVICE;
+		for (int i = 0; i < n; ++i)
+			if (device_ordinals[i] < 0 || device_ordinals[i] >= count) return SDFR_ERR_INVALID_ARGUMENT;
+		int rc = need_rccl(nullptr);
+		if (rc != SDFR_OK) return rc;
+		std::vector<ncclComm_t> comms((size_t)n, nullptr);
+		SDFR_NCCL(nullptr, rccl().comm_init_all(comms.data(), n, device_ordinals));
+		for (int i = 0; i < n; ++i)
+		{
+			sdfr_comm *c = new sdfr_comm();
+			c->comm = comms[(size_t)i];
+			c->rank = i;
+			c->world = n;
+			c->device = device_ordinals[i];
+			out_n[i] = c;
+		}
+		return SDFR_OK;
+	});
 }
 
 // Teardown of a communicator, bounded in time.
@@ -396,6 +402,11 @@ struct CloseJob
 	std::condition_variable cv;
 	bool done = false;
 	std::atomic<const char *> stage{"not started"};
+	// set by the caller BEFORE it calls ncclCommAbort: abort reclaims the communicator, so a helper that it releases from
+	// ncclCommFinalize must not go on to ncclCommDestroy (a second destroy of freed memory)
+	// Both flags change under `m`: whichever side gets there first decides -- the helper claims the destroy, or the caller
+	// claims the abort; never both.
+	bool aborted = false, destroying = false;
 	ncclResult_t finalize_rc = ncclSuccess, destroy_rc = ncclSuccess;
 };
 double close_timeout_s()
@@ -411,102 +422,132 @@ double close_timeout_s()
 
 int sdfr_comm_close(sdfr_comm *c)
 {
-	if (!c) return SDFR_ERR_INVALID_ARGUMENT;
-	Rccl &n = rccl();
-	int status = SDFR_OK;
-	std::string diagnosis;
-	if (c->comm && n.ok)
-	{
-		(void)hipSetDevice(c->device);
+	return guarded(nullptr, [&]() -> int {
+		if (!c) return SDFR_ERR_INVALID_ARGUMENT;
+		Rccl &n = rccl();
+		int status = SDFR_OK;
+		std::string diagnosis;
+		if (c->comm && n.ok)
 		{
-			// drain the streams its transfers ran on, and let go of the handles
-			std::lock_guard<std::mutex> g(g_registry_lock);
-			for (sdfr_renderer *r : c->users)
+			(void)hipSetDevice(c->device);
 			{
-				if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
-				for (size_t k = 0; k < r->comms_used.size(); ++k)
-					if (r->comms_used[k] == c) { r->comms_used.erase(r->comms_used.begin() + (long)k); break; }
-			}
-			c->users.clear();
-		}
-		if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-		auto job = std::make_shared<CloseJob>();
-		const ncclComm_t comm = c->comm;
-		const int device = c->device;
-		std::thread worker([job, comm, device, &n]() {
-			(void)hipSetDevice(device);
-			if (n.comm_finalize)
-			{
-				job->stage = "ncclCommFinalize";
-				job->finalize_rc = n.comm_finalize(comm);
-				// a non-blocking communicator finishes in the background: ncclInProgress until it has
-				while (n.comm_async_error && job->finalize_rc == ncclInProgress)
+				// drain the streams its transfers ran on, and let go of the handles
+				std::lock_guard<std::mutex> g(g_registry_lock);
+				for (sdfr_renderer *r : c->users)
 				{
-					ncclResult_t state = ncclSuccess;
-					if (n.comm_async_error(comm, &state) != ncclSuccess || state != ncclInProgress) { job->finalize_rc = state; break; }
-					std::this_thread::sleep_for(std::chrono::milliseconds(5));
+					if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+					for (size_t k = 0; k < r->comms_used.size(); ++k)
+						if (r->comms_used[k] == c) { r->comms_used.erase(r->comms_used.begin() + (long)k); break; }
+				}
+				c->users.clear();
+			}
+			if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+			auto job = std::make_shared<CloseJob>();
+			const ncclComm_t comm = c->comm;
+			const int device = c->device;
+			std::thread worker([job, comm, device, &n]() {
+				(void)hipSetDevice(device);
+				if (n.comm_finalize)
+				{
+					job->stage = "ncclCommFinalize";
+					job->finalize_rc = n.comm_finalize(comm);
+					// a non-blocking communicator finishes in the background: ncclInProgress until it has
+					while (n.comm_async_error && job->finalize_rc == ncclInProgress)
+					{
+						ncclResult_t state = ncclSuccess;
+						if (n.comm_async_error(comm, &state) != ncclSuccess || state != ncclInProgress) { job->finalize_rc = state; break; }
+						std::this_thread::sleep_for(std::chrono::milliseconds(5));
+					}
+				}
+				// destroy only what is still ours and was finalized: not after the caller's abort, not after a failed finalize
+				bool mine = false;
+				{
+					std::lock_guard<std::mutex> g(job->m);
+					mine = !job->aborted && job->finalize_rc == ncclSuccess;
+					job->destroying = mine;
+				}
+				if (mine)
+				{
+					job->stage = "ncclCommDestroy";
+					job->destroy_rc = n.comm_destroy(comm);
+				}
+				job->stage = "done";
+				std::lock_guard<std::mutex> g(job->m);
+				job->done = true;
+				job->cv.notify_all();
+			});
+			const auto wait_for = [&](double seconds) {
+				std::unique_lock<std::mutex> g(job->m);
+				return job->cv.wait_for(g, std::chrono::duration<double>(seconds), [&] { return job->done; });
+			};
+			if (wait_for(close_timeout_s()))
+			{
+				worker.join();
+				if (job->finalize_rc != ncclSuccess)
+				{
+					status = SDFR_ERR_COMM;
+					diagnosis = std::string("ncclCommFinalize: ") + n.error_string(job->finalize_rc) + " (the communicator was not destroyed)";
+				}
+				else if (job->destroy_rc != ncclSuccess)
+				{
+					status = SDFR_ERR_COMM;
+					diagnosis = std::string("ncclCommDestroy: ") + n.error_string(job->destroy_rc);
 				}
 			}
-			job->stage = "ncclCommDestroy";
-			job->destroy_rc = n.comm_destroy(comm);
-			job->stage = "done";
-			std::lock_guard<std::mutex> g(job->m);
-			job->done = true;
-			job->cv.notify_all();
-		});
-		const auto wait_for = [&](double seconds) {
-			std::unique_lock<std::mutex> g(job->m);
-			return job->cv.wait_for(g, std::chrono::duration<double>(seconds), [&] { return job->done; });
-		};
-		if (wait_for(close_timeout_s()))
-		{
-			worker.join();
-			if (job->destroy_rc != ncclSuccess)
+			else
 			{
+				const char *stuck_in = job->stage.load();
 				status = SDFR_ERR_COMM;
-				diagnosis = std::string("ncclCommDestroy: ") + n.error_string(job->destroy_rc);
+				diagnosis = std::string("communicator teardown did not finish within ") + std::to_string(close_timeout_s()) + " s; last seen in " + stuck_in;
+				// abort only a teardown that is stuck BEFORE the destroy: a helper inside ncclCommDestroy already owns the
+				// communicator's memory, and aborting under it would free it twice
+				bool may_abort = false;
+				{
+					std::lock_guard<std::mutex> g(job->m);
+					may_abort = n.comm_abort && !job->destroying && !job->done;
+					job->aborted = may_abort;
+				}
+				if (may_abort)
+				{
+					(void)n.comm_abort(comm);
+					diagnosis += wait_for(5.0) ? "; ncclCommAbort released it" : "; ncclCommAbort did not release it: the helper thread and the communicator are left behind";
+				}
+				else if (n.comm_abort && !job->done)
+					diagnosis += "; stuck inside the destroy itself: not aborted (the helper thread and the communicator are left behind)";
+				if (job->finalize_rc != ncclSuccess && job->finalize_rc != ncclInProgress) diagnosis += std::string("; ncclCommFinalize had returned: ") + n.error_string(job->finalize_rc);
+				if (job->done) worker.join(); else worker.detach(); // `job` is shared: the thread may outlive this call
+				const auto files = mapped_rccl_files();
+				diagnosis += "; librccl in use: " + n.path + ", distinct librccl files mapped: " + std::to_string(files.size());
 			}
 		}
-		else
+		if (status != SDFR_OK)
 		{
-			const char *stuck_in = job->stage.load();
-			status = SDFR_ERR_COMM;
-			diagnosis = std::string("communicator teardown did not finish within ") + std::to_string(close_timeout_s()) + " s; last seen in " + stuck_in;
-			if (n.comm_abort)
-			{
-				(void)n.comm_abort(comm);
-				diagnosis += wait_for(5.0) ? "; ncclCommAbort released it" : "; ncclCommAbort did not release it: the helper thread and the communicator are left behind";
-			}
-			if (job->done) worker.join(); else worker.detach(); // `job` is shared: the thread may outlive this call
-			const auto files = mapped_rccl_files();
-			diagnosis += "; librccl in use: " + n.path + ", distinct librccl files mapped: " + std::to_string(files.size());
+			g_comm_error = diagnosis;
+			fprintf(stderr, "libsdfr: %s\n", diagnosis.c_str());
 		}
-	}
-	if (status != SDFR_OK)
-	{
-		g_comm_error = diagnosis;
-		fprintf(stderr, "libsdfr: %s\n", diagnosis.c_str());
-	}
-	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-	delete c;
-	return status;
+		if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+		delete c;
+		return status;
+	});
 }
 
 void sdfr_comm_destroy(sdfr_comm *c) { (void)sdfr_comm_close(c); }
 
 int sdfr_comm_library_info(char *path_out, size_t path_bytes, int *nccl_version, int *copies_mapped)
 {
-	const int rc = need_rccl(nullptr);
-	if (rc != SDFR_OK) return rc;
-	Rccl &n = rccl();
-	if (path_out && path_bytes) snprintf(path_out, path_bytes, "%s", n.path.c_str());
-	if (nccl_version)
-	{
-		*nccl_version = 0;
-		if (n.get_version) (void)n.get_version(nccl_version);
-	}
-	if (copies_mapped) *copies_mapped = (int)mapped_rccl_files().size();
-	return SDFR_OK;
+	return guarded(nullptr, [&]() -> int {
+		const int rc = need_rccl(nullptr);
+		if (rc != SDFR_OK) return rc;
+		Rccl &n = rccl();
+		if (path_out && path_bytes) snprintf(path_out, path_bytes, "%s", n.path.c_str());
+		if (nccl_version)
+		{
+			*nccl_version = 0;
+			if (n.get_version) (void)n.get_version(nccl_version);
+		}
+		if (copies_mapped) *copies_mapped = (int)mapped_rccl_files().size();
+		return SDFR_OK;
+	});
 }
 
 int sdfr_comm_rank(const sdfr_comm *c) { return c ? c->rank : SDFR_ERR_INVALID_ARGUMENT; }
@@ -516,120 +557,126 @@ const char *sdfr_comm_last_error(const sdfr_comm *c) { return c ? c->error.c_str
 // (drains `hip_stream` before it returns: nothing of it is pending when the communicator is closed)
 int sdfr_comm_selftest(sdfr_comm *c, size_t bytes, void *hip_stream)
 {
-	if (!c || bytes == 0 || bytes > ((size_t)1 << 30)) return SDFR_ERR_INVALID_ARGUMENT;
-	hipStream_t stream = (hipStream_t)hip_stream;
-	if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, "hipSetDevice failed");
-	// never RCCL on the legacy NULL stream (see sdfr_comm_close): the call is blocking anyway, so the NULL stream is
-	// drained and the exchange runs on a stream of the communicator's own.  SDFR_COMM_ALLOW_NULL_STREAM=1 (diagnosis
-	// only) keeps the caller's NULL stream.
-	if (!stream && !getenv("SDFR_COMM_ALLOW_NULL_STREAM"))
-	{
-		if (hipStreamSynchronize(nullptr) != hipSuccess) return comm_fail(c, "hipStreamSynchronize(NULL) failed");
-		if (!c->own_stream && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return comm_fail(c, "hipStreamCreate failed");
-		stream = c->own_stream;
-	}
-	const int to = (c->rank + 1) % c->world, from = (c->rank + c->world - 1) % c->world;
-	auto pattern = [](int rank, size_t i) { return (unsigned char)((i * 2654435761u + (size_t)rank * 97u + (i >> 13)) & 0xffu); };
-	std::vector<unsigned char> host(bytes);
-	for (size_t i = 0; i < bytes; ++i) host[i] = pattern(c->rank, i);
-	unsigned char *d_send = nullptr, *d_recv = nullptr;
-	hipError_t e = hipMalloc((void **)&d_send, bytes);
-	if (e == hipSuccess) e = hipMalloc((void **)&d_recv, bytes);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_send, host.data(), bytes, hipMemcpyHostToDevice, stream);
-	if (e == hipSuccess) e = hipMemsetAsync(d_recv, 0, bytes, stream);
-	int rc = e == hipSuccess ? SDFR_OK : comm_fail(c, std::string("selftest buffers: ") + hipGetErrorString(e));
-	if (rc == SDFR_OK)
-	{
-		Rccl &n = rccl();
-		ncclResult_t nrc = n.group_start();
-		if (nrc == ncclSuccess) nrc = n.send(d_send, bytes, ncclInt8, to, c->comm, stream);
-		if (nrc == ncclSuccess) nrc = n.recv(d_recv, bytes, ncclInt8, from, c->comm, stream);
-		const ncclResult_t erc = n.group_end();
-		if (nrc == ncclSuccess) nrc = erc;
-		if (nrc != ncclSuccess) rc = nccl_fail(c, nrc, "selftest send/recv");
-	}
-	if (rc == SDFR_OK)
-	{
-		e = hipMemcpyAsync(host.data(), d_recv, bytes, hipMemcpyDeviceToHost, stream);
-		if (e == hipSuccess) e = hipStreamSynchronize(stream);
-		if (e != hipSuccess) rc = comm_fail(c, std::string("selftest read-back: ") + hipGetErrorString(e));
-	}
-	if (rc == SDFR_OK)
-	{
-		size_t bad = 0;
-		for (size_t i = 0; i < bytes; ++i) bad += host[i] != pattern(from, i);
-		if (bad) rc = comm_fail(c, "selftest: " + std::to_string(bad) + " of " + std::to_string(bytes) + " bytes from rank " + std::to_string(from) + " differ");
-	}
-	(void)hipFree(d_send);
-	(void)hipFree(d_recv);
-	return rc;
+	return guarded(nullptr, [&]() -> int {
+		if (!c || bytes == 0 || bytes > ((size_t)1 << 30)) return SDFR_ERR_INVALID_ARGUMENT;
+		hipStream_t stream = (hipStream_t)hip_stream;
+		if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, "hipSetDevice failed");
+		// never RCCL on the legacy NULL stream (see sdfr_comm_close): the call is blocking anyway, so the NULL stream is
+		// drained and the exchange runs on a stream of the communicator's own.  SDFR_COMM_ALLOW_NULL_STREAM=1 (diagnosis
+		// only) keeps the caller's NULL stream.
+		if (!stream && !getenv("SDFR_COMM_ALLOW_NULL_STREAM"))
+		{
+			if (hipStreamSynchronize(nullptr) != hipSuccess) return comm_fail(c, "hipStreamSynchronize(NULL) failed");
+			if (!c->own_stream && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return comm_fail(c, "hipStreamCreate failed");
+			stream = c->own_stream;
+		}
+		const int to = (c->rank + 1) % c->world, from = (c->rank + c->world - 1) % c->world;
+		auto pattern = [](int rank, size_t i) { return (unsigned char)((i * 2654435761u + (size_t)rank * 97u + (i >> 13)) & 0xffu); };
+		std::vector<unsigned char> host(bytes);
+		for (size_t i = 0; i < bytes; ++i) host[i] = pattern(c->rank, i);
+		unsigned char *d_send = nullptr, *d_recv = nullptr;
+		hipError_t e = hipMalloc((void **)&d_send, bytes);
+		if (e == hipSuccess) e = hipMalloc((void **)&d_recv, bytes);
+		if (e == hipSuccess) e = hipMemcpyAsync(d_send, host.data(), bytes, hipMemcpyHostToDevice, stream);
+		if (e == hipSuccess) e = hipMemsetAsync(d_recv, 0, bytes, stream);
+		int rc = e == hipSuccess ? SDFR_OK : comm_fail(c, std::string("selftest buffers: ") + hipGetErrorString(e));
+		if (rc == SDFR_OK)
+		{
+			Rccl &n = rccl();
+			ncclResult_t nrc = n.group_start();
+			if (nrc == ncclSuccess) nrc = n.send(d_send, bytes, ncclInt8, to, c->comm, stream);
+			if (nrc == ncclSuccess) nrc = n.recv(d_recv, bytes, ncclInt8, from, c->comm, stream);
+			const ncclResult_t erc = n.group_end();
+			if (nrc == ncclSuccess) nrc = erc;
+			if (nrc != ncclSuccess) rc = nccl_fail(c, nrc, "selftest send/recv");
+		}
+		if (rc == SDFR_OK)
+		{
+			e = hipMemcpyAsync(host.data(), d_recv, bytes, hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(stream);
+			if (e != hipSuccess) rc = comm_fail(c, std::string("selftest read-back: ") + hipGetErrorString(e));
+		}
+		if (rc == SDFR_OK)
+		{
+			size_t bad = 0;
+			for (size_t i = 0; i < bytes; ++i) bad += host[i] != pattern(from, i);
+			if (bad) rc = comm_fail(c, "selftest: " + std::to_string(bad) + " of " + std::to_string(bytes) + " bytes from rank " + std::to_string(from) + " differ");
+		}
+		(void)hipFree(d_send);
+		(void)hipFree(d_recv);
+		return rc;
+	});
 }
 
 int sdfr_render_gather(sdfr_renderer *r, sdfr_comm *c, int width, int height, void *root_image, int image_format, int wire_format)
 {
-	GatherShape g;
-	int rc = gather_check(r, c, width, height, root_image, image_format, wire_format, g);
-	if (rc != SDFR_OK) return rc;
-	comm_remember_renderer(c, r);
-	rc = gather_render(r, c, g);
-	if (rc != SDFR_OK) return rc;
-	r->have_xfer = false;
-	if (g.world > 1 && g.rank_bytes)
-	{
-		Rccl &n = rccl();
-		SDFR_HIP(hipEventRecord(r->ev_xfer[0], r->comm_stream));
-		ncclResult_t nrc = n.group_start();
-		if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupStart"), c->error);
-		rc = gather_transfer(r, c, g);
-		nrc = n.group_end();
+	return guarded(r, [&]() -> int {
+		GatherShape g;
+		int rc = gather_check(r, c, width, height, root_image, image_format, wire_format, g);
 		if (rc != SDFR_OK) return rc;
-		if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupEnd"), c->error);
-		SDFR_HIP(hipEventRecord(r->ev_xfer[1], r->comm_stream));
-		r->have_xfer = true;
-		r->xfer_bytes = c->rank == 0 ? (size_t)(g.world - 1) * g.rank_bytes : g.rank_bytes;
-	}
-	return gather_finish(r, c, g, root_image);
+		comm_remember_renderer(c, r);
+		rc = gather_render(r, c, g);
+		if (rc != SDFR_OK) return rc;
+		r->have_xfer = false;
+		if (g.world > 1 && g.rank_bytes)
+		{
+			Rccl &n = rccl();
+			SDFR_HIP(hipEventRecord(r->ev_xfer[0], r->comm_stream));
+			ncclResult_t nrc = n.group_start();
+			if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupStart"), c->error);
+			rc = gather_transfer(r, c, g);
+			nrc = n.group_end();
+			if (rc != SDFR_OK) return rc;
+			if (nrc != ncclSuccess) return fail(r, nccl_fail(c, nrc, "ncclGroupEnd"), c->error);
+			SDFR_HIP(hipEventRecord(r->ev_xfer[1], r->comm_stream));
+			r->have_xfer = true;
+			r->xfer_bytes = c->rank == 0 ? (size_t)(g.world - 1) * g.rank_bytes : g.rank_bytes;
+		}
+		return gather_finish(r, c, g, root_image);
+	});
 }
 
 int sdfr_render_gather_all(sdfr_renderer *const *r, sdfr_comm *const *c, int n, int width, int height, void *root_image, int image_format,
 	int wire_format)
 {
-	if (!r || !c || n < 1 || n > 64) return SDFR_ERR_INVALID_ARGUMENT;
-	std::vector<GatherShape> g((size_t)n);
-	for (int i = 0; i < n; ++i)
-	{
-		if (!r[i] || !c[i] || c[i]->rank != i || c[i]->world != n) return SDFR_ERR_INVALID_ARGUMENT;
-		const int rc = gather_check(r[i], c[i], width, height, root_image, image_format, wire_format, g[(size_t)i]);
-		if (rc != SDFR_OK) return rc;
-		if (g[(size_t)i].rank_bytes != g[0].rank_bytes) return fail(r[i], SDFR_ERR_INVALID_ARGUMENT, "the handles carry different strip splits");
-	}
-	for (int i = 0; i < n; ++i)
-	{
-		comm_remember_renderer(c[i], r[i]);
-		const int rc = gather_render(r[i], c[i], g[(size_t)i]);
-		if (rc != SDFR_OK) return rc;
-	}
-	if (n > 1 && g[0].rank_bytes)
-	{
-		Rccl &nc = rccl();
-		ncclResult_t nrc = nc.group_start();
-		if (nrc != ncclSuccess) return fail(r[0], nccl_fail(c[0], nrc, "ncclGroupStart"), c[0]->error);
-		int rc = SDFR_OK;
-		for (int i = 0; i < n && rc == SDFR_OK; ++i)
+	return guarded(nullptr, [&]() -> int {
+		if (!r || !c || n < 1 || n > 64) return SDFR_ERR_INVALID_ARGUMENT;
+		std::vector<GatherShape> g((size_t)n);
+		for (int i = 0; i < n; ++i)
 		{
-			(void)hipSetDevice(r[i]->device);
-			rc = gather_transfer(r[i], c[i], g[(size_t)i]);
+			if (!r[i] || !c[i] || c[i]->rank != i || c[i]->world != n) return SDFR_ERR_INVALID_ARGUMENT;
+			const int rc = gather_check(r[i], c[i], width, height, root_image, image_format, wire_format, g[(size_t)i]);
+			if (rc != SDFR_OK) return rc;
+			if (g[(size_t)i].rank_bytes != g[0].rank_bytes) return fail(r[i], SDFR_ERR_INVALID_ARGUMENT, "the handles carry different strip splits");
 		}
-		nrc = nc.group_end();
-		if (rc != SDFR_OK) return rc;
-		if (nrc != ncclSuccess) return fail(r[0], nccl_fail(c[0], nrc, "ncclGroupEnd"), c[0]->error);
-	}
-	for (int i = 0; i < n; ++i)
-	{
-		const int rc = gather_finish(r[i], c[i], g[(size_t)i], root_image);
-		if (rc != SDFR_OK) return rc;
-	}
-	return SDFR_OK;
+		for (int i = 0; i < n; ++i)
+		{
+			comm_remember_renderer(c[i], r[i]);
+			const int rc = gather_render(r[i], c[i], g[(size_t)i]);
+			if (rc != SDFR_OK) return rc;
+		}
+		if (n > 1 && g[0].rank_bytes)
+		{
+			Rccl &nc = rccl();
+			ncclResult_t nrc = nc.group_start();
+			if (nrc != ncclSuccess) return fail(r[0], nccl_fail(c[0], nrc, "ncclGroupStart"), c[0]->error);
+			int rc = SDFR_OK;
+			for (int i = 0; i < n && rc == SDFR_OK; ++i)
+			{
+				(void)hipSetDevice(r[i]->device);
+				rc = gather_transfer(r[i], c[i], g[(size_t)i]);
+			}
+			nrc = nc.group_end();
+			if (rc != SDFR_OK) return rc;
+			if (nrc != ncclSuccess) return fail(r[0], nccl_fail(c[0], nrc, "ncclGroupEnd"), c[0]->error);
+		}
+		for (int i = 0; i < n; ++i)
+		{
+			const int rc = gather_finish(r[i], c[i], g[(size_t)i], root_image);
+			if (rc != SDFR_OK) return rc;
+		}
+		return SDFR_OK;
+	});
 }
 
 } // extern "C"

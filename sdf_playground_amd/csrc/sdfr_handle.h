@@ -9,6 +9,8 @@
 #include "sdfr_jit.h"
 #include "sdfr_kernels.h"
 
+#include <cstdio>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -64,22 +66,39 @@ struct sdfr_renderer
 	size_t wire_bytes = 0;
 	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
 	std::vector<void *> comms_used; // sdfr_comm* whose transfers ran on comm_stream (sdfr_comm.cpp keeps both sides of the list)
-
-	// peer-copy gather (sdfr_peer.hip): rank 0 owns the region, the peers map it through hipIpc
-	void *peer_buffer = nullptr;    // the gathered buffer (rank 0's memory)
-	uint32_t *peer_flags = nullptr; // [0..63] arrived[rank], [64] released, [65] timed out
-	size_t peer_capacity = 0;
-	int peer_world = 0;
-	bool peer_owner = false;
-	uint32_t peer_frame = 0;        // frames gathered through this region so far
-	uint32_t *peer_status = nullptr, *d_peer_status = nullptr; // this rank's "a wait gave up" word: mapped host memory, host / device view
-	uint32_t *d_peer_gave_up = nullptr;                        // the same word in device memory: what the kernels that follow a wait look at
 };
 
 static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)
 {
 	if (r) r->error = msg;
 	return code;
+}
+// No C++ exception crosses the C boundary: every extern "C" entry point with a body of more than a line runs inside this
+// (std::bad_alloc, std::regex_error from the scene translation, std::system_error from a thread that cannot start ...
+// would otherwise reach a C or ctypes caller as std::terminate -> abort()).
+template <class F>
+static inline int guarded(const sdfr_renderer *r, F body) noexcept
+{
+	try
+	{
+		return body();
+	}
+	catch (const std::exception &e)
+	{
+		try
+		{
+			if (r) r->error = std::string("internal error: ") + e.what();
+			fprintf(stderr, "libsdfr: internal error: %s\n", e.what());
+		}
+		catch (...)
+		{
+		}
+		return SDFR_ERR_INTERNAL;
+	}
+	catch (...)
+	{
+		return SDFR_ERR_INTERNAL;
+	}
 }
 static inline int hip_fail(const sdfr_renderer *r, hipError_t e, const char *what)
 {
@@ -101,7 +120,7 @@ bool is_wire_format(int format);
 int render_impl(sdfr_renderer *r, int width, int height, int rank, int world, void *out, int format, int out_on_host, uint32_t *pixel_stats,
 	RenderMode mode, RenderTotals *totals = nullptr);
 
-// the stream and events shared by the RCCL and the peer-copy transports of a gathered frame (sdfr_comm.cpp)
+// the stream and events of a gathered frame (sdfr_comm.cpp)
 int gather_prepare_streams(sdfr_renderer *r);
 // the handle is going away: communicators that remember it must forget it (sdfr_comm.cpp)
 void comm_forget_renderer(sdfr_renderer *r);

@@ -32,9 +32,8 @@ hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &r
 	RenderTotals *totals, const WavefrontWorkspace &ws, hipStream_t stream, hipEvent_t *march_events, hipEvent_t *shade_events,
 	int *n_rounds_out);
 
-// skip_if_set (optional, device-visible): the kernel does nothing if the word is non-zero when it starts (peer-copy gather)
 hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, int priv_count,
-	int priv_period, hipStream_t stream, const uint32_t *skip_if_set = nullptr);
+	int priv_period, hipStream_t stream);
 
 // HDR::process: scene16/bloom1 RGBA16F, ldr8 RGBA8, all device pointers of width*height pixels
 // mid_event (optional) is recorded between the two kernels

@@ -269,10 +269,8 @@ hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_w
 // pixel.  RGBA32F / RGBA16F strips are copied; packed strips (12-byte float or 6-byte half rgb
 // triples, then one flag byte per pixel, per rank) expand to RGBA32F / RGBA16F.
 __global__ __launch_bounds__(SDFR_BLOCK) void k_assemble(int width, int height, int world, size_t strip_pixels, const uint32_t *gathered,
-	uint32_t *image, int format, int priv_count, int priv_period, const uint32_t *skip_if_set)
+	uint32_t *image, int format, int priv_count, int priv_period)
 {
-	// the peer-copy gather: a wait before this launch gave up, the slots are not this frame's (sdfr_peer.hip)
-	if (skip_if_set && *skip_if_set != 0u) return; // device memory, written by a kernel before this one on the stream
 	const uint32_t px = blockIdx.x * SDFR_BLOCK + threadIdx.x, py = blockIdx.y;
 	if (px >= (uint32_t)width) return;
 	uint32_t strip = py >> 3; // becomes the index among the shared strips
@@ -423,12 +421,12 @@ hipError_t launch_wavefront_schedule(int scene, const FrameU &U, const RowMap &r
 }
 
 hipError_t launch_assemble_strips(int width, int height, int world, const void *gathered, void *out_image, int format, int priv_count,
-	int priv_period, hipStream_t stream, const uint32_t *skip_if_set)
+	int priv_period, hipStream_t stream)
 {
 	const size_t strips = ((size_t)height + 7) / 8 - private_strip_count((uint32_t)(((size_t)height + 7) / 8), priv_count, priv_period);
 	const size_t strip_pixels = ((strips + world - 1) / world) * 8 * (size_t)width;
 	hipLaunchKernelGGL(k_assemble, dim3((width + SDFR_BLOCK - 1) / SDFR_BLOCK, height), dim3(SDFR_BLOCK), 0, stream, width, height, world, strip_pixels,
-		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), format, priv_count, priv_period, skip_if_set);
+		reinterpret_cast<const uint32_t *>(gathered), reinterpret_cast<uint32_t *>(out_image), format, priv_count, priv_period);
 	return hipGetLastError();
 }
 

@@ -97,16 +97,3 @@ def test_bench_n_ranks_rehearsed_on_one_gpu(ranks, extra):
     if "--private-strips" in extra:
         assert d["config"]["strip_calibration"]["private_strips_of_16"] == 5
         assert per_rank[0]["rays"] > per_rank[1]["rays"]  # rank 0 keeps 5 of every 16 strips for itself
-
-
-@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--private-strips", "5"]), (2, ["--wire", "f32"])])
-def test_bench_peer_copy_transport_with_real_ranks_on_one_gpu(ranks, extra):
-    """--transport ipc: the library's gather without a collective library (sdfr_render_gather_peer): N rank processes
-    on the one GPU, the peers copy their strips into rank 0's buffer through hipIpc mappings, flag words order the
-    frames (three in flight), rank 0 assembles.  Image bit-equal to a direct render, counters add up, no wait gave up."""
-    d = _run(["--gpus", str(ranks), "--transport", "ipc"] + extra)
-    assert d["verified"] is True and d["n_gpus"] == ranks and d["config"]["transport"].startswith("sdfr_render_gather_peer")
-    per_rank = d["config"]["per_rank"]
-    assert [p["rank"] for p in per_rank] == list(range(ranks)) and all(p["rays"] > 0 for p in per_rank)
-    assert abs(sum(p["rays"] for p in per_rank) / d["steps"] / (328 * 205) - d["config"]["rays_per_pixel"]) < 1e-9
-    assert d["config"]["frames_in_flight"] == 3

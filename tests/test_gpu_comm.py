@@ -181,43 +181,3 @@ def test_half_wire_format_emulated_worlds(scene_renderer, world, split):
             assert np.array_equal(host[:7 * n], got[:7 * n]), rank
             assert np.array_equal(sp.unpack_strip16_host(got, n).view(np.uint16), plain[rank].to(torch.float16).cpu().numpy().view(np.uint16))
     r.setSchedule(1)
-
-
-def test_peer_copy_gather_world_one_and_a_peer_that_never_arrives(scene_renderer):
-    """sdfr_render_gather_peer on one rank equals a direct render; with a region made for two ranks and no second
-    rank, rank 0's wait gives up after its 2 s and says so instead of hanging the GPU"""
-    import torch
-    import sdf_playground_amd as sp
-
-    r = scene_renderer
-    full16 = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
-    r.render(None, W, H, out=full16, fmt=sp.RGBA16F)
-    ref = r.getStats()
-    r.peerRegionCreate(sp.strip_buffer_bytes(W, H, 1, sp.STRIP_RGB16F_A8), 1)
-    out = torch.full((H, W, 4), -3.0, dtype=torch.float16, device="cuda")
-    for _ in range(3):
-        r.renderGatherPeer(0, 1, W, H, out=out, fmt=sp.RGBA16F)
-    r.peerRegionStatus()
-    assert torch.equal(out.view(torch.int16), full16.view(torch.int16))
-    s = r.getStats()
-    assert (s.pixels, s.rays, s.march_evals, s.hits) == (ref.pixels, ref.rays, ref.march_evals, ref.hits)
-    with pytest.raises(sp.SdfrError):
-        r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)  # the region was made for a world of one
-    r.peerRegionCreate(2 * sp.strip_buffer_bytes(W, H, 2, sp.STRIP_RGB16F_A8), 2)
-    out.fill_(-7.0)
-    r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)      # nobody plays rank 1
-    with pytest.raises(sp.SdfrError) as e:
-        r.peerRegionStatus()
-    assert e.value.code == -8 and "did not arrive" in str(e.value)
-    # the frame whose wait gave up was NOT assembled out of half-filled slots (round-2 review: no torn frames) ...
-    assert bool((out == -7.0).all())
-    # ... the region is stale from then on: the next frame is refused at once, without a synchronisation ...
-    with pytest.raises(sp.SdfrError) as e:
-        r.renderGatherPeer(0, 2, W, H, out=out, fmt=sp.RGBA16F)
-    assert e.value.code == -8 and "stale" in str(e.value)
-    # ... and a new region starts clean
-    r.peerRegionCreate(sp.strip_buffer_bytes(W, H, 1, sp.STRIP_RGB16F_A8), 1)
-    r.renderGatherPeer(0, 1, W, H, out=out, fmt=sp.RGBA16F)
-    r.peerRegionStatus()
-    assert torch.equal(out.view(torch.int16), full16.view(torch.int16))
-    r.peerRegionClose()
