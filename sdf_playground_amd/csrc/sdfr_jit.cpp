@@ -213,7 +213,9 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	pk.rm.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
 	uint32_t name_hash = 2166136261u; // a run-time scene is known by its name
 	for (char ch : js.name) name_hash = (name_hash ^ (unsigned char)ch) * 16777619u;
-	pk.rm.feedback_key = mode.persistent ? pixel_feedback_key(0x80000000u | name_hash | (frame_needs_debug(U) ? 1u : 0u), U.width, pk.rm) : 0u;
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	const uint32_t feedback_rows = !mode.persistent ? 0u : pk.rm.unit_log2 ? pk.rm.units : ((n_work + bt - 1u) / bt) / tiles_x;
+	pk.rm.feedback_key = mode.persistent ? pixel_feedback_key(0x80000000u | name_hash | (frame_needs_debug(U) ? 1u : 0u), U.width, pk.rm, feedback_rows) : 0u;
 	pk.n_work = hand_out_items;
 	pk.format = format;
 	pk.out = out;
@@ -227,9 +229,7 @@ hipError_t jit_launch_pixel(const JitScene &js, const FrameU &U, const RowMap &r
 	void *args[] = {&pk};
 	const hipError_t e = hipModuleLaunchKernel(fn, blocks, 1, 1, bt, 1, 1, 0, stream, args, nullptr);
 	if (e != hipSuccess) return e;
-	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
-	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors, !mode.persistent ? 0u : pk.rm.unit_log2 ? pk.rm.units : ((n_work + bt - 1u) / bt) / tiles_x,
-		(unsigned long long)n_work, pk.rm.feedback_key);
+	return launch_reduce_totals(partials, blocks, totals, stream, ws.tile_cursors, feedback_rows, (unsigned long long)n_work, pk.rm.feedback_key);
 }
 
 } // namespace sdfr

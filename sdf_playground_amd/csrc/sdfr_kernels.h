@@ -51,8 +51,10 @@ hipError_t launch_wavefront_init(const FrameU &U, const RowMap &rm, uint32_t n_w
 // feedback_rows: tile rows of the launch if it was a persistent one whose rows should be re-ordered for the next frame (else 0)
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,
 	uint32_t feedback_rows, unsigned long long frame_pixels, uint32_t feedback_key);
-// RowMap::feedback_key of a launch: scene (index, or a hash of a run-time scene's name), frame width and what the row map selects
-uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm);
+// RowMap::feedback_key of a launch: scene (index, or a hash of a run-time scene's name), frame width and what the row map selects,
+// hashed into the upper 22 bits; the low 10 bits ARE the number of units (tile rows or squares, <= SDFR_ROW_FEEDBACK_MAX = 512) the
+// order was made for: two launches with equal keys have equally long orders whatever the hash does
+uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm, uint32_t feedback_rows);
 int pixel_tile_cursor_words();
 int scene_tile_w_log2(int scene); // the tile shape a built-in scene asks for (SceneTileShape); 3 = 8 x 8, also for run-time scenes
 // how the pixel kernels are launched: persistent (resident waves pull tiles from the cursors) or one wave per

@@ -192,15 +192,18 @@ uint32_t pixel_launch_blocks(const PixelLaunchMode &mode, uint32_t tiles, uint32
 	return blocks < tiles ? blocks : tiles;
 }
 
-uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm)
+uint32_t pixel_feedback_key(uint32_t scene_key, int width, const RowMap &rm, uint32_t feedback_rows)
 {
+	static_assert(SDFR_ROW_FEEDBACK_MAX < 1024u, "the unit count rides in the key's low 10 bits");
+	if (feedback_rows > SDFR_ROW_FEEDBACK_MAX) return 0u; // no feedback for such a launch (the kernel and the fold agree: fb_rows <= MAX)
 	// FNV-1a over what a row order depends on; never 0
 	uint32_t h = 2166136261u;
 	const uint32_t words[] = {scene_key, (uint32_t)width, (uint32_t)rm.local_rows, (uint32_t)rm.rank, (uint32_t)rm.world, (uint32_t)rm.tile_w_log2,
 		(uint32_t)rm.priv_count, (uint32_t)rm.priv_period, (uint32_t)rm.direct, rm.unit_log2};
 	for (uint32_t w : words)
 		for (int b = 0; b < 4; ++b) h = (h ^ ((w >> (8 * b)) & 0xffu)) * 16777619u;
-	return h ? h : 1u;
+	h = (h & ~1023u) | feedback_rows;
+	return h ? h : 1024u;
 }
 
 hipError_t launch_reduce_totals(const RenderTotals *partials, uint32_t n_blocks, RenderTotals *totals, hipStream_t stream, uint32_t *tile_cursors,

@@ -331,7 +331,9 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	if ((size_t)hand_out_items > ws.capacity) return hipErrorInvalidValue; // one counter record per block, at most one block per tile handed out
 	const uint32_t blocks = pixel_launch_blocks(mode, (hand_out_items + SDFR_PIXEL_BLOCK - 1) / SDFR_PIXEL_BLOCK, (uint32_t)device_cu_count(device) * per_cu);
 	rows.retire_after = mode.persistent ? (uint32_t)mode.retire_after : 0u;
-	rows.feedback_key = mode.persistent ? pixel_feedback_key((uint32_t)scene_index * 2u + (DBG ? 1u : 0u), U.width, rows) : 0u;
+	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
+	const uint32_t feedback_rows = !mode.persistent ? 0u : rows.unit_log2 ? rows.units : tiles_blocks / tiles_x;
+	rows.feedback_key = mode.persistent ? pixel_feedback_key((uint32_t)scene_index * 2u + (DBG ? 1u : 0u), U.width, rows, feedback_rows) : 0u;
 	PixelKernelArgs args;
 	args.U = U;
 	args.rm = rows;
@@ -345,10 +347,9 @@ static hipError_t run_pixel(const FrameU &U, const RowMap &rm, void *out, int fo
 	args.cap = ws.capacity;
 	args.tile_cursors = mode.persistent ? ws.tile_cursors : (uint32_t *)nullptr;
 	hipLaunchKernelGGL((k_pixel<Scene, DBG>), dim3(blocks), dim3(SDFR_PIXEL_BLOCK), 0, stream, args);
-	const uint32_t tiles_x = ((uint32_t)U.width + (1u << rm.tile_w_log2) - 1u) >> rm.tile_w_log2;
 	// (the fold leaves frames with many rays per pixel in image order, SDFR_ROW_FEEDBACK_MAX_RAYS: a rule about tile ROWS -- their queue records
 	// are contiguous in image order --, not about squares, which scatter them either way)
-	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, !mode.persistent ? 0u : rows.unit_log2 ? rows.units : tiles_blocks / tiles_x,
+	return launch_reduce_totals(ws.partials, blocks, totals, stream, ws.tile_cursors, feedback_rows,
 		rows.unit_log2 ? ~0ull >> 8 : (unsigned long long)n_work, rows.feedback_key);
 }
 

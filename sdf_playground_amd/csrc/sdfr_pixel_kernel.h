@@ -18,6 +18,9 @@ namespace sdfr {
 #ifndef SDFR_PIXEL_BLOCK
 #define SDFR_PIXEL_BLOCK 64
 #endif
+// the pixel kernel is ONE WAVE PER BLOCK: lane_now() indexes the LDS columns, a block's tile-queue slot and its counter record
+// are the wave's (TileQueue::start(blockIdx.x), partials[blockIdx.x]); two waves in a block would share them
+static_assert(SDFR_PIXEL_BLOCK == 64, "the pixel kernel is one wave per block");
 #define SDFR_INVALID_PIXEL 0xffffffffu
 #ifdef SDFR_MAX_WAVES_PER_BLOCK
 static_assert(SDFR_BLOCK <= 64 * SDFR_MAX_WAVES_PER_BLOCK && SDFR_PIXEL_BLOCK <= 64 * SDFR_MAX_WAVES_PER_BLOCK, "per-wave LDS of the scenes");
