@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--iters", type=int, default=256)
+    ap.add_argument("--config", default=None, help="a BASELINE configuration of bench.py (2, 3, 4, 5, 5g): its scene, size, limits and camera sweep")
     a = ap.parse_args()
     if a.build:
         from sdf_playground_amd import buildlib
@@ -34,14 +35,26 @@ def main():
     import sdf_playground_amd as sp
     from quickbench import camera_for
 
+    cfg = None
+    if a.config:
+        import bench
+        cfg = bench.CONFIGS[a.config]
+        a.scene, a.width, a.height = cfg["scene"], cfg["width"], cfg["height"]
     r = sp.SDFRenderer(0)
     r.initShader(a.scene)
     r.setSchedule(1)
     r.setLimits(iter_count=a.iters)
+    if cfg:
+        r.setLimits(**cfg["limits"])
     out = torch.empty((a.height, a.width, 4), dtype=torch.float32, device="cuda")
     for k in range(a.frames):
-        r.setParameters(k / 60.0)
-        r.render(camera_for(a.scene, k, a.width, a.height), a.width, a.height, out=out)
+        if cfg:
+            cam, stime = bench.make_camera(k, config=a.config)
+            r.setParameters(stime)
+            r.render(cam, a.width, a.height, out=out)
+        else:
+            r.setParameters(k / 60.0)
+            r.render(camera_for(a.scene, k, a.width, a.height), a.width, a.height, out=out)
         s = r.getStats()
         tot = max(1, s.pixels)
         other = s.pixels - s.rays - s.march_evals - s.hits
