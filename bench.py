@@ -874,35 +874,35 @@ def run(a, world):
         if verified is not None:
             out["verified"] = verified
         if not distributed and not a.no_second_pass:
-            # Not the headline: the same sweep with TWO frames in flight (two handles on two streams),
-            # measured after the timed region.  It shows how much of `ms_per_step` is the tail of a
-            # frame (the last few waves march their long rays alone); `value` and `roofline` above
-            # stay on one frame in flight, where a kernel's duration is its own.
+            # Not the headline: the same sweep with TWO frames in flight inside the one handle (sdfr_set_frames_in_flight(2): two
+            # internal streams and workspaces, frames rendered into two images in turn), measured after the timed region.  It shows
+            # how much of `ms_per_step` is the tail of a frame (the last few waves march their long rays alone); `value` and
+            # `roofline` above stay on one frame in flight, where a kernel's duration is its own.
             try:
-                s2 = torch.cuda.Stream()
-                r2 = make_renderer(s2)
                 img2 = torch.empty_like(image)
-                pair = [(r, image), (r2, img2)]
+                images2 = [image, img2]
+                r.sync()
+                r.setFramesInFlight(2)
 
                 def step2(k):
-                    h_, im_ = pair[k & 1]
-                    h_.setParameters(cameras[k % SWEEP][1])
-                    h_.setCamera(cameras[k % SWEEP][0])
-                    h_.render(None, W, H, out=im_)
+                    r.setParameters(cameras[k % SWEEP][1])
+                    r.setCamera(cameras[k % SWEEP][0])
+                    r.render(None, W, H, out=images2[k & 1])
 
                 for k in range(4):
                     step2(k)
-                torch.cuda.synchronize()
+                r.sync()
                 t2 = time.perf_counter()
                 for k in range(a.steps):
                     step2(k)
-                torch.cuda.synchronize()
+                r.sync()
                 ms2 = (time.perf_counter() - t2) / max(1, a.steps) * 1e3
                 out["two_frames_in_flight"] = {"ms_per_step": ms2, "value": total_rays / a.steps / (ms2 * 1e-3) / 1e6, "unit": "Mrays/s",
-                                               "note": "informational: same frames, two streams; not the headline"}
-                r2.close()
+                                               "note": "informational: same frames, sdfr_set_frames_in_flight(2) on the one handle; not the headline"}
             except Exception as e:
                 out["two_frames_in_flight"] = {"error": repr(e)}
+            finally:
+                r.setFramesInFlight(1)
         if not distributed and not a.no_extra_passes:
             # Informational passes over the same 16 sweep frames, after the timed region, one frame in flight:
             #   exact_steps        every step of every ray marched (sdfr_set_step_shortcuts off): the reference's own step count

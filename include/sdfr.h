@@ -284,6 +284,21 @@ int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_
 
 int sdfr_sync(sdfr_renderer *r);
 
+/* ---- two frames in flight inside one handle (no counterpart: D3D11's immediate context pipelines the reference's draws by itself)
+ *      The end of a frame runs on a nearly empty chip -- the last waves finishing their tiles -- and only the NEXT frame can fill it
+ *      (DESIGN.md 4.1).  With n = 2 sdfr_render alternates between two internal streams, each with a workspace of its own (the
+ *      memory of the ray queue twice), so that frame k + 1 starts while frame k drains; pixels and counters are those of n = 1.
+ *        - sdfr_render returns at once, as always; the frames of one handle may finish out of order.
+ *        - the stream given to sdfr_set_stream is not used while n = 2: order other work against a frame with
+ *          sdfr_wait_frame(r, stream) -- `stream` waits (on the device, not the host) for the frame submitted last -- or sdfr_sync,
+ *          which waits for both frames.  sdfr_get_stats / sdfr_get_timings report the frame submitted last (and wait for it).
+ *        - two frames in flight write two buffers: a frame rendered into memory that overlaps the destination of the frame still in
+ *          flight waits for that frame first (correct, but nothing overlaps) -- alternate between two images.
+ *        - sdfr_render_strips / _gather / sdfr_postprocess run on the lane of the frame submitted last.
+ *      n = 1 (the default) returns to one stream (the caller's) after waiting for both frames. ------------------------------------- */
+int sdfr_set_frames_in_flight(sdfr_renderer *r, int n);
+int sdfr_wait_frame(sdfr_renderer *r, void *hip_stream);
+
 /* ---- observability: GPUProfiler::profile("setup"/"draw") (SDFRenderer.cpp:100,104) ---------- */
 typedef struct sdfr_stats
 {

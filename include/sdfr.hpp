@@ -112,6 +112,9 @@ public:
 		return sdfr_render(handle, width, height, target, format, target_on_host ? 1 : 0, nullptr) == SDFR_OK;
 	}
 
+	// two frames in flight inside this renderer (sdfr_set_frames_in_flight): render into two targets in turn, sync() waits for both
+	bool setFramesInFlight(int n) { return sdfr_set_frames_in_flight(handle, n) == SDFR_OK; }
+	bool sync() { return sdfr_sync(handle) == SDFR_OK; }
 	const char *lastError() const { return sdfr_last_error(handle); }
 	sdfr_renderer *native() { return handle; }
 

@@ -123,6 +123,7 @@ const std::vector<SceneEntry> &test_scenes()
 {
 	static const std::vector<SceneEntry> table = {
 		{"debug_materials", "", {}, &ps_main<SceneDebugMaterials>},
+		{"light_shadows_backwards", "", {}, &ps_main<SceneLightShadowsT<true>>}, // scenes.h: for Images/multi-lights.png only
 		{"normal_test", "VAR_round(min = 0.0001, max = 0.05, start = 0.01) VAR_analytic(min = 0, max = 1, step = 1, start = 1)", {"round", "analytic"},
 			&ps_main<SceneNormalTest>},
 		// the VAR_ tags of sdf_playground_amd/scenes/noise_lod.hlsl and dialect_tour.hlsl, in the order of the text

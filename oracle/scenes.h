@@ -456,9 +456,14 @@ struct SceneGems
 };
 
 // ---- scenes/sdf_scene_light_shadows.hlsl -------------------------------------------
-struct SceneLightShadows
+// BACKWARDS = false is the scene file as it stands.  BACKWARDS = true steps the five lights' phases the other way (time -= 2 pi / 5):
+// a guess at the older version of this file that the reference's own screenshot Images/multi-lights.png was taken with -- there the
+// lights stand where today's file puts them and wear the colours in reverse order (tests/test_reference_images_cpu.py); it exists for
+// that comparison only ("light_shadows_backwards", oracle_api.cpp: test scenes).
+template <bool BACKWARDS>
+struct SceneLightShadowsT
 {
-	static const char *name() { return "light_shadows"; }
+	static const char *name() { return BACKWARDS ? "light_shadows_backwards" : "light_shadows"; }
 	// :5-11
 	static float3 color_from_index(uint index)
 	{
@@ -484,7 +489,7 @@ struct SceneLightShadows
 		real spheres[5];
 		for (uint i = 0; i < 5; ++i)
 		{
-			time += real(pi) * real(2.f) / real(5.f);
+			time = BACKWARDS ? time - real(pi) * real(2.f) / real(5.f) : time + real(pi) * real(2.f) / real(5.f);
 			real sphere_x = r_cos(time * real(1.f)) * real(-5.f);
 			real sphere_y = (r_cos(time * real(2.f)) * real(-0.5f) + real(0.5f)) * real(2.f) + real(1.f);
 			real sphere_z = r_sin(time * real(2.f)) * real(2.f);
@@ -526,7 +531,7 @@ struct SceneLightShadows
 		real time = F.stime * real(0.25f);
 		for (uint i = 0; i < 5; ++i)
 		{
-			time += real(pi) * real(2.f) / real(5.f);
+			time = BACKWARDS ? time - real(pi) * real(2.f) / real(5.f) : time + real(pi) * real(2.f) / real(5.f);
 			real sphere_x = r_cos(time * real(1.f)) * real(-5.f);
 			real sphere_y = (r_cos(time * real(2.f)) * real(-0.5f) + real(0.5f)) * real(2.f) + real(0.5f);
 			real sphere_z = r_sin(time * real(2.f)) * real(2.f);
@@ -542,5 +547,6 @@ struct SceneLightShadows
 	}
 	static float3 map_background(const Frame &F, float3 dir, uint) { return sky_color(dir, F.stime); }
 };
+typedef SceneLightShadowsT<false> SceneLightShadows;
 
 } // namespace orc

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_load_scene_hlsl", "sdfr_check_scene_hlsl", "sdfr_translate_scene_hlsl", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
+    "sdfr_sync", "sdfr_set_frames_in_flight", "sdfr_wait_frame", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_load_scene_hlsl", "sdfr_check_scene_hlsl", "sdfr_translate_scene_hlsl", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_close", "sdfr_comm_library_info", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
@@ -157,6 +157,8 @@ def load_library():
     L.sdfr_render_strips.argtypes = [vp, ci, ci, ci, ci, vp, ci]
     L.sdfr_assemble_strips.argtypes = [vp, ci, ci, ci, vp, vp, ci]
     L.sdfr_sync.argtypes = [vp]
+    L.sdfr_set_frames_in_flight.argtypes = [vp, ci]
+    L.sdfr_wait_frame.argtypes = [vp, vp]
     L.sdfr_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.sdfr_get_timings.argtypes = [vp, ctypes.POINTER(_CTiming), ci]
     L.sdfr_postprocess.argtypes = [vp, ci, ci, vp, vp, vp]
@@ -526,6 +528,16 @@ class SDFRenderer:
 
     def sync(self):
         self._check(self._L.sdfr_sync(self._h))
+
+    def setFramesInFlight(self, n):
+        """sdfr_set_frames_in_flight: 2 = render() alternates between two internal streams and workspaces, so that a frame starts
+        while the one before drains (render into two images in turn; sync() waits for both); 1 = the default."""
+        self._check(self._L.sdfr_set_frames_in_flight(self._h, int(n)))
+
+    def waitFrame(self, stream=None):
+        """sdfr_wait_frame: `stream` (a raw hipStream_t / torch stream's .cuda_stream; None = the default stream) waits on the
+        device for the frame submitted last"""
+        self._check(self._L.sdfr_wait_frame(self._h, ctypes.c_void_p(stream)))
 
     def getStats(self):
         s = Stats()

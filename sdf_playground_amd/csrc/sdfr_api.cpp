@@ -103,7 +103,92 @@ static int ensure_workspace(sdfr_renderer *r, size_t pixels, bool wavefront)
 	return SDFR_OK;
 }
 
+// ---- two frames in flight (sdfr_set_frames_in_flight): see sdfr_renderer::Lane -----------------------------------
+static void swap_lanes(sdfr_renderer *r)
+{
+	std::swap(r->stream, r->other.stream);
+	std::swap(r->ws, r->other.ws);
+	std::swap(r->wavefront_capacity, r->other.wavefront_capacity);
+	std::swap(r->d_totals, r->other.d_totals);
+	std::swap(r->totals_parts, r->other.totals_parts);
+	std::swap(r->ev_begin, r->other.ev_begin);
+	std::swap(r->ev_end, r->other.ev_end);
+	std::swap(r->have_render, r->other.have_render);
+	std::swap(r->out_lo, r->other.out_lo);
+	std::swap(r->out_hi, r->other.out_hi);
+}
+static void release_second_lane(sdfr_renderer *r)
+{
+	if (r->frames_in_flight != 2) return;
+	(void)hipStreamSynchronize(r->stream);
+	(void)hipStreamSynchronize(r->other.stream);
+	swap_lanes(r); // free_workspace works on the current lane
+	free_workspace(r);
+	swap_lanes(r);
+	(void)hipFree(r->other.d_totals);
+	if (r->other.ev_begin) (void)hipEventDestroy(r->other.ev_begin);
+	if (r->other.ev_end) (void)hipEventDestroy(r->other.ev_end);
+	r->other = sdfr_renderer::Lane();
+	for (hipStream_t &s : r->lane_streams)
+	{
+		if (s) (void)hipStreamDestroy(s);
+		s = nullptr;
+	}
+	r->stream = r->user_stream;
+	r->frames_in_flight = 1;
+}
+
 extern "C" {
+
+int sdfr_set_frames_in_flight(sdfr_renderer *r, int n)
+{
+	return guarded(r, [&]() -> int {
+		if (!r || (n != 1 && n != 2)) return SDFR_ERR_INVALID_ARGUMENT;
+		SDFR_HIP(hipSetDevice(r->device));
+		if (n == r->frames_in_flight) return SDFR_OK;
+		if (n == 1)
+		{
+			release_second_lane(r);
+			return SDFR_OK;
+		}
+		SDFR_HIP(hipStreamSynchronize(r->stream));
+		sdfr_renderer::Lane lane;
+		hipError_t e = hipStreamCreateWithFlags(&r->lane_streams[0], hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->lane_streams[1], hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipMalloc((void **)&lane.d_totals, 2 * sizeof(RenderTotals));
+		if (e == hipSuccess) e = hipEventCreate(&lane.ev_begin);
+		if (e == hipSuccess) e = hipEventCreate(&lane.ev_end);
+		if (e != hipSuccess)
+		{
+			(void)hipFree(lane.d_totals);
+			if (lane.ev_begin) (void)hipEventDestroy(lane.ev_begin);
+			if (lane.ev_end) (void)hipEventDestroy(lane.ev_end);
+			for (hipStream_t &s : r->lane_streams)
+			{
+				if (s) (void)hipStreamDestroy(s);
+				s = nullptr;
+			}
+			return hip_fail(r, e, "sdfr_set_frames_in_flight");
+		}
+		lane.stream = r->lane_streams[1];
+		r->other = lane;
+		r->stream = r->lane_streams[0]; // the current lane keeps its workspace and the row order it has learned
+		r->out_lo = r->out_hi = nullptr;
+		r->frames_in_flight = 2;
+		return SDFR_OK;
+	});
+}
+
+int sdfr_wait_frame(sdfr_renderer *r, void *hip_stream)
+{
+	return guarded(r, [&]() -> int {
+		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
+		if (!r->have_render) return SDFR_OK;
+		SDFR_HIP(hipSetDevice(r->device));
+		SDFR_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, r->ev_end, 0));
+		return SDFR_OK;
+	});
+}
 
 int sdfr_create(int device_ordinal, sdfr_renderer **out)
 {
@@ -160,6 +245,7 @@ void sdfr_destroy(sdfr_renderer *r)
 	(void)hipStreamSynchronize(r->stream);
 	if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
 	comm_forget_renderer(r);
+	release_second_lane(r); // waits for it, frees its workspace, counters, events and the two internal streams
 	free_workspace(r);
 	jit_unload(r->jit);
 	(void)hipFree(r->d_totals);
@@ -190,7 +276,8 @@ int sdfr_set_stream(sdfr_renderer *r, void *hip_stream)
 {
 	return guarded(r, [&]() -> int {
 		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
-		r->stream = (hipStream_t)hip_stream;
+		r->user_stream = (hipStream_t)hip_stream;
+		if (r->frames_in_flight == 1) r->stream = r->user_stream; // (two frames in flight run on the handle's own two streams)
 		return SDFR_OK;
 	});
 }
@@ -307,6 +394,7 @@ int sdfr_load_scene_hlsl(sdfr_renderer *r, const char *name, const char *hlsl_so
 		std::string err;
 		if (!jit_compile(r->device, name, hlsl_scene_source(hlsl_source), slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
 		SDFR_HIP(hipStreamSynchronize(r->stream));
+		if (r->frames_in_flight == 2) SDFR_HIP(hipStreamSynchronize(r->other.stream)); // the frame before may still run the old module
 		jit_unload(r->jit);
 		r->jit = js;
 		r->vars = vm;
@@ -331,6 +419,7 @@ int sdfr_load_scene_source(sdfr_renderer *r, const char *name, const char *sourc
 		// (SceneManager.cpp:118-127 keeps the old shader and shows the compiler's message)
 		if (!jit_compile(r->device, name, source, slots, js, err)) return fail(r, SDFR_ERR_COMPILE, err);
 		SDFR_HIP(hipStreamSynchronize(r->stream));
+		if (r->frames_in_flight == 2) SDFR_HIP(hipStreamSynchronize(r->other.stream));
 		jit_unload(r->jit);
 		r->jit = js;
 		r->vars = vm;
@@ -742,6 +831,20 @@ extern "C" {
 int sdfr_render(sdfr_renderer *r, int width, int height, void *out, int format, int out_on_host, uint32_t *pixel_stats)
 {
 	return guarded(r, [&]() -> int {
+		if (r && r->frames_in_flight == 2 && out && width > 0 && height > 0)
+		{
+			// the lane of the frame before last takes this one; its stream orders it behind that frame (same workspace)
+			SDFR_HIP(hipSetDevice(r->device));
+			swap_lanes(r);
+			const char *lo = out_on_host ? nullptr : (const char *)out;
+			const char *hi = lo ? lo + image_bytes((size_t)width * height, format) : nullptr;
+			// the frame still in flight on the other lane writes [other.out_lo, other.out_hi): the same memory twice in a row is
+			// a hazard between the two streams
+			if (lo && r->other.out_lo && lo < r->other.out_hi && r->other.out_lo < hi && r->other.have_render)
+				SDFR_HIP(hipStreamWaitEvent(r->stream, r->other.ev_end, 0));
+			r->out_lo = lo;
+			r->out_hi = hi;
+		}
 		return render_impl(r, width, height, 0, 1, out, format, out_on_host, pixel_stats, RENDER_FULL);
 	});
 }
@@ -854,6 +957,7 @@ int sdfr_sync(sdfr_renderer *r)
 	return guarded(r, [&]() -> int {
 		if (!r) return SDFR_ERR_INVALID_ARGUMENT;
 		SDFR_HIP(hipStreamSynchronize(r->stream));
+		if (r->frames_in_flight == 2) SDFR_HIP(hipStreamSynchronize(r->other.stream));
 		return SDFR_OK;
 	});
 }

@@ -66,6 +66,28 @@ struct sdfr_renderer
 	size_t wire_bytes = 0;
 	bool caller_times = false; // render_impl leaves ev_begin / ev_end to its caller
 	std::vector<void *> comms_used; // sdfr_comm* whose transfers ran on comm_stream (sdfr_comm.cpp keeps both sides of the list)
+
+	// Two frames in flight inside one handle (sdfr_set_frames_in_flight).  What a frame in flight owns -- its stream, its
+	// workspace (ray queue, counter records, tile cursors with the row order learned from ITS last frame), its counters
+	// and its two events -- is a Lane; the members above (`stream`, `ws`, `wavefront_capacity`, `d_totals`, `totals_parts`,
+	// `ev_begin`, `ev_end`, `have_render`) are the CURRENT lane's, `other` is the lane of the frame before.  sdfr_render swaps the two
+	// before it launches, so everything else in the library keeps working on "the handle's stream and workspace".
+	struct Lane
+	{
+		hipStream_t stream = nullptr;
+		sdfr::WavefrontWorkspace ws = {};
+		size_t wavefront_capacity = 0;
+		sdfr::RenderTotals *d_totals = nullptr;
+		int totals_parts = 1;
+		hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+		bool have_render = false;
+		const char *out_lo = nullptr, *out_hi = nullptr; // device range its last frame was rendered into
+	};
+	int frames_in_flight = 1;
+	Lane other;
+	hipStream_t lane_streams[2] = {nullptr, nullptr}; // the library's own streams while frames_in_flight == 2
+	hipStream_t user_stream = nullptr;                // what sdfr_set_stream gave (in use while frames_in_flight == 1)
+	const char *out_lo = nullptr, *out_hi = nullptr;  // the current lane's
 };
 
 static inline int fail(const sdfr_renderer *r, int code, const std::string &msg)

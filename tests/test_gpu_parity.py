@@ -491,3 +491,75 @@ def test_registered_host_target(renderer, oracle):
     finally:
         renderer.registerHostTarget(None)
     assert np.array_equal(renderer.render(None, W, H).view(np.uint32), ref.view(np.uint32))
+
+
+def test_two_frames_in_flight_inside_one_handle(renderer, oracle):
+    """sdfr_set_frames_in_flight(2): render() alternates between two internal streams and workspaces.  A sequence of frames
+    (moving camera, a change of size, a change of scene, the same buffer twice in a row) gives, frame for frame, the pixels
+    and counters of the same sequence rendered one frame at a time."""
+    import torch
+    import bench
+    import sdf_playground_amd as sp
+
+    def sequence(pipelined):
+        renderer.setFramesInFlight(2 if pipelined else 1)
+        frames = []
+        try:
+            for scene, config in (("labyrinth", "3"), ("cube_sea", "2"), ("gems", "5g")):
+                _setup(renderer, oracle, scene, 0.75)
+                renderer.setLimits(**bench.CONFIGS[config]["limits"])
+                bufs = {}
+                for k in range(7):
+                    w, h = ((960, 540), (960, 540), (648, 360), (960, 540), (960, 540), (500, 281), (960, 540))[k]
+                    cam, stime = bench.make_camera(k, w, h, config)
+                    renderer.setParameters(stime)
+                    # two images per size, taken in turn -- except frames 3 and 4, which go into the SAME image (the second one
+                    # has to wait for the first: sdfr.h)
+                    pair = bufs.setdefault((w, h), [torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(2)])
+                    img = pair[0] if k in (3, 4) else pair[k & 1]
+                    renderer.render(cam, w, h, out=img)
+                    s = renderer.getStats()  # waits for this frame only
+                    frames.append((scene, k, img.clone(), (s.pixels, s.rays, s.march_evals, s.hits)))
+            renderer.sync()
+        finally:
+            renderer.setFramesInFlight(1)
+        return frames
+
+    one = sequence(False)
+    two = sequence(True)
+    assert len(one) == len(two) == 21
+    for a, b in zip(one, two):
+        assert a[3] == b[3] and a[3][0] > 0, (a[0], a[1], a[3], b[3])
+        assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)), (a[0], a[1])
+    # without a wait in between, frames in flight still land in their own images
+    renderer.setFramesInFlight(2)
+    try:
+        _setup(renderer, oracle, "labyrinth", 0.75)
+        renderer.setLimits(**bench.CONFIGS["3"]["limits"])
+        imgs = [torch.full((540, 960, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+        for k in range(4):
+            cam, stime = bench.make_camera(k, 960, 540, "3")
+            renderer.setParameters(stime)
+            renderer.render(cam, 960, 540, out=imgs[k])
+        side = torch.cuda.Stream()
+        renderer.waitFrame(side.cuda_stream)  # the side stream waits on the device for frame 3
+        with torch.cuda.stream(side):
+            copy3 = imgs[3].clone()
+        renderer.sync()
+        side.synchronize()
+        for k in range(4):
+            ref = [f for f in one if f[0] == "labyrinth" and f[1] == k][0] if k not in (2,) else None
+            if ref is not None and ref[2].shape == imgs[k].shape:
+                assert torch.equal(ref[2].view(torch.int32), imgs[k].view(torch.int32)), k
+        assert torch.equal(copy3.view(torch.int32), imgs[3].view(torch.int32))
+        # the same image twice in a row, nothing waited for in between: the second frame is what stays
+        same = torch.full((540, 960, 4), -1.0, dtype=torch.float32, device="cuda")
+        for k in (3, 4):
+            cam, stime = bench.make_camera(k, 960, 540, "3")
+            renderer.setParameters(stime)
+            renderer.render(cam, 960, 540, out=same)
+        renderer.sync()
+        ref4 = [f for f in one if f[0] == "labyrinth" and f[1] == 4][0]
+        assert torch.equal(ref4[2].view(torch.int32), same.view(torch.int32))
+    finally:
+        renderer.setFramesInFlight(1)
