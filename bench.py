@@ -44,7 +44,7 @@ SPLIT_PERIOD = 16     # strips per period of the private/shared split (N > 1)
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (spec); 2 flop per lane per FMA at the packed rate
 PEAK_VALU_LANE_OPS = 78.6e12      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: what the VALU can issue, one op per lane per cycle
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md (spec)
-PROFILE_ROUND = "r03"   # the round whose committed counter profiles (profiles/pmc_<round>_cfg<c>.json) feed `roofline.executed`
+PROFILE_ROUND = "r04"   # the round whose committed counter profiles (profiles/pmc_<round>_cfg<c>.json) feed `roofline.executed`
 CENSUS_FILE = os.path.join(ROOT, "profiles", "census_r03.json")
 
 

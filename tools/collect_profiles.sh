@@ -5,7 +5,7 @@
 #   tools/collect_profiles.sh <round> <config> [pmc]      e.g.  r02 3 pmc     (pmc: also the counter passes)
 # Outputs under gpurun_out/<round>/cfg<config>/ ; tools/profiles_to_repo.py turns them into profiles/.
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 C=${2:-3}
 OUT=gpurun_out/$R/cfg$C
 mkdir -p $OUT

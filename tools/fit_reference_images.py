@@ -42,6 +42,7 @@ TARGETS = {
     "cube-sea": ("cube-sea.png", "cube_sea", None, {}),
     "labyrinth": ("labyrinth.png", "labyrinth", None, {}),
     "gems": ("gems.png", "gems", None, {}),
+    "table": ("table.png", "table", None, {}),
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
     "multi-lights-todays-file": ("multi-lights.png", "light_shadows", None, {}),
@@ -229,6 +230,32 @@ def scan_time(name, p, times, s=4, sigma=1.0, variables=None):
         res.append((obj(q), float(t)))
     res.sort()
     return res
+
+
+def floor_equivalents(name, p, reach=6, s=8, sigma=1.0, times=None, keep=6):
+    """The checker floor (sdf_common.hlsl:24-59) looks the same from eye + (a, b) with a + b even, and after a quarter turn about a tile
+    centre: a fit that locked onto the floor -- most of most screenshots -- may have the scene's objects in the wrong place.  Tries the
+    equivalent cameras (and `times`, if what distinguishes them moves) and returns the best `keep` as (loss, params)."""
+    _file, scene, _g, _v = TARGETS[name]
+    obj = Objective(name, scene, load_reference(name), s, sigma)
+    p = np.asarray(p, float)
+    c = np.array([0.5, 0.5])
+    out = []
+    for k in range(4):
+        ang = k * math.pi / 2
+        ca, sa = math.cos(-ang), math.sin(-ang)
+        e = np.array([p[0], p[2]]) - c
+        e2 = c + np.array([ca * e[0] - sa * e[1], sa * e[0] + ca * e[1]])
+        for a in range(-reach, reach + 1):
+            for b in range(-reach, reach + 1):
+                if (a + b) % 2:
+                    continue
+                for t in (times if times is not None else [p[5]]):
+                    q = p.copy()
+                    q[0], q[2], q[3], q[5] = e2[0] + a, e2[1] + b, p[3] + ang, t
+                    out.append((obj(q), q))
+    out.sort(key=lambda x: x[0])
+    return out[:keep]
 
 
 class FullObjective:

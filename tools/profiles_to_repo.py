@@ -15,7 +15,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 config = sys.argv[2] if len(sys.argv) > 2 else "3"
 src = os.path.join(ROOT, "gpurun_out", rnd, "cfg" + config)
 dst = os.path.join(ROOT, "profiles")
