@@ -43,6 +43,7 @@ TARGETS = {
     "labyrinth": ("labyrinth.png", "labyrinth", None, {}),
     "gems": ("gems.png", "gems", None, {}),
     "table": ("table.png", "table", None, {}),
+    "transparency": ("transparency.png", "basic_transparency", None, {}),
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
     "multi-lights-todays-file": ("multi-lights.png", "light_shadows", None, {}),

@@ -12,10 +12,11 @@ import sdf_playground_amd as sp
 from quickbench import camera_for
 
 W, H = 3840, 2160
+ONLY = sys.argv[sys.argv.index("--scenes") + 1:] if "--scenes" in sys.argv else None  # a few scenes only (A/B of one scene's change)
 r = sp.SDFRenderer(0)
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 print("scene                 ms/frame   Mrays/s  rays/px  evals/ray")
-for scene in sp.scene_names():
+for scene in (ONLY or sp.scene_names()):
     r.initShader(scene)
     r.setLimits(iter_count=256)
     ms, st = [], None
@@ -27,6 +28,9 @@ for scene in sp.scene_names():
             ms.append(st.ms_gpu)
     m = float(np.median(ms))
     print("%-20s %9.3f %9.1f %8.2f %10.1f" % (scene, m, st.rays / m / 1e3, st.rays / st.pixels, st.march_evals / max(1, st.rays)), flush=True)
+if ONLY:
+    r.close()
+    sys.exit(0)
 r.initShader("labyrinth")
 r.setLimits(iter_count=256)
 cam = camera_for("labyrinth", 1, W, H)
