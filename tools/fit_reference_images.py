@@ -44,6 +44,8 @@ TARGETS = {
     "gems": ("gems.png", "gems", None, {}),
     "table": ("table.png", "table", None, {}),
     "transparency": ("transparency.png", "basic_transparency", None, {}),
+    "shell": ("shell.png", "shell", None, {}),
+    "sierpinski": ("sierpinski.png", "sierpinski", None, {}),
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
     "multi-lights-todays-file": ("multi-lights.png", "light_shadows", None, {}),
