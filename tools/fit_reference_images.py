@@ -45,6 +45,7 @@ TARGETS = {
     "table": ("table.png", "table", None, {}),
     "transparency": ("transparency.png", "basic_transparency", None, {}),
     "shell": ("shell.png", "shell", None, {}),
+    "distortion": ("distortion.png", "distortion", None, {}),
     "sierpinski": ("sierpinski.png", "sierpinski", None, {}),
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
