@@ -338,6 +338,10 @@ int sdfr_get_timings(sdfr_renderer *r, sdfr_timing *out, int capacity);
  *   what = 2, constant c negative control: a * (1/c) vs IEEE divide on the same inputs (> 0)
  *   what = 3, constant c as 1 but for a = +-0 and all 2^-60 <= |a| <= 2^40 (fast ground plane) */
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches);
+/* Throws a C++ exception inside the library the way an allocation failure or a regex error would (what = 0: std::runtime_error,
+ * 1: std::bad_alloc, 2: something that is not a std::exception) and returns what the guard at the C boundary makes of it:
+ * SDFR_ERR_INTERNAL, with the exception's words in sdfr_last_error(r) when r is not NULL.  Needs no device; r may be NULL. */
+int sdfr_selftest_exception(sdfr_renderer *r, int what);
 
 #ifdef __cplusplus
 }

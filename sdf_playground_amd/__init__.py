@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "sdfr_current_scene", "sdfr_var_count", "sdfr_var_info", "sdfr_var_set", "sdfr_var_get", "sdfr_vars_reset", "sdfr_set_camera",
     "sdfr_set_camera_lookat", "sdfr_set_camera_direction", "sdfr_get_camera", "sdfr_set_time", "sdfr_get_limits", "sdfr_set_limits",
     "sdfr_set_schedule", "sdfr_set_profiling", "sdfr_strip_buffer_pixels", "sdfr_render", "sdfr_render_strips", "sdfr_assemble_strips",
-    "sdfr_sync", "sdfr_set_frames_in_flight", "sdfr_wait_frame", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_load_scene_hlsl", "sdfr_check_scene_hlsl", "sdfr_translate_scene_hlsl", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
+    "sdfr_sync", "sdfr_set_frames_in_flight", "sdfr_wait_frame", "sdfr_get_stats", "sdfr_selftest_math", "sdfr_selftest_exception", "sdfr_postprocess", "sdfr_load_scene_source", "sdfr_check_scene_source", "sdfr_load_scene_hlsl", "sdfr_check_scene_hlsl", "sdfr_translate_scene_hlsl", "sdfr_get_timings", "sdfr_strip_buffer_bytes",
     "sdfr_set_strip_split", "sdfr_strip_buffer_pixels_split", "sdfr_strip_buffer_bytes_split", "sdfr_render_private_strips",
     "sdfr_comm_unique_id", "sdfr_comm_create", "sdfr_comm_create_all", "sdfr_comm_destroy", "sdfr_comm_close", "sdfr_comm_library_info", "sdfr_comm_rank", "sdfr_comm_world",
     "sdfr_comm_last_error", "sdfr_comm_selftest", "sdfr_render_gather", "sdfr_render_gather_all", "sdfr_set_launch_mode", "sdfr_set_step_shortcuts",
@@ -163,6 +163,7 @@ def load_library():
     L.sdfr_get_timings.argtypes = [vp, ctypes.POINTER(_CTiming), ci]
     L.sdfr_postprocess.argtypes = [vp, ci, ci, vp, vp, vp]
     L.sdfr_selftest_math.argtypes = [vp, ci, cf, ctypes.POINTER(ctypes.c_uint64)]
+    L.sdfr_selftest_exception.argtypes = [vp, ci]
     L.sdfr_comm_unique_id.argtypes = [vp]
     L.sdfr_comm_create.argtypes = [vp, ci, ci, ci, ctypes.POINTER(vp)]
     L.sdfr_comm_create_all.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]

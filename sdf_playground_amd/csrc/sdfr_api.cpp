@@ -900,6 +900,16 @@ int sdfr_postprocess(sdfr_renderer *r, int width, int height, const void *scene_
 	});
 }
 
+int sdfr_selftest_exception(sdfr_renderer *r, int what)
+{
+	return guarded(r, [&]() -> int {
+		if (what == 0) throw std::runtime_error("sdfr_selftest_exception: thrown on purpose");
+		if (what == 1) throw std::bad_alloc();
+		if (what == 2) throw 42;
+		return SDFR_OK;
+	});
+}
+
 int sdfr_selftest_math(sdfr_renderer *r, int what, float constant, uint64_t *mismatches)
 {
 	return guarded(r, [&]() -> int {

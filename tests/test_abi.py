@@ -65,3 +65,12 @@ def test_strip_layout_host_statement():
             strip = row // 8
             gathered[rank, (strip // world) * 8 + row % 8] = img[row]
     assert np.array_equal(sp.assemble_strips_host(w, h, world, gathered.reshape(world, n, 2)), img)
+
+
+def test_no_cpp_exception_crosses_the_c_boundary(lib):
+    """every C entry point with a body runs inside guarded() (csrc/sdfr_handle.h): an exception thrown inside the library -- the
+    self-test throws a std::runtime_error, a std::bad_alloc and a non-std object on purpose -- comes back as SDFR_ERR_INTERNAL;
+    a ctypes (or C) caller would otherwise die of std::terminate.  Needs no device."""
+    for what in (0, 1, 2):
+        assert lib.sdfr_selftest_exception(None, what) == -9
+    assert lib.sdfr_selftest_exception(None, 3) == 0

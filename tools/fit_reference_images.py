@@ -178,8 +178,10 @@ def fit(name, p0, spread, variables=None, fit_vars=(), var0=(), var_spread=(), q
     return best[0][1], best[0][0]
 
 
-def global_search(name, lo, hi, n, s=16, sigma=2.0, keep=24, seed=7, variables=None, verbose=True):
-    """n quasi-random cameras in the box [lo, hi], the `keep` best refined by Nelder-Mead at (s, sigma); returns them sorted."""
+def global_search(name, lo, hi, n, s=16, sigma=2.0, keep=24, seed=7, variables=None, verbose=True, recheck=0):
+    """n quasi-random cameras in the box [lo, hi], the `keep` best refined by Nelder-Mead at (s, sigma); returns them sorted.
+    recheck: that many of the best are looked at again at every 8th pixel with half the blur before the `keep` are chosen -- from a
+    high camera a far checker floor is uniformly grey at the coarse level, and every camera over it looks equally good."""
     from scipy.stats import qmc
 
     _file, scene, _g, _v = TARGETS[name]
@@ -191,6 +193,12 @@ def global_search(name, lo, hi, n, s=16, sigma=2.0, keep=24, seed=7, variables=N
     cands = sorted(((obj(p), tuple(p)) for p in pts), key=lambda c: c[0])
     if verbose:
         print("  global: %d samples in %.0f s, best %.5f, %d-th %.5f" % (n, time.time() - t0, cands[0][0], keep, cands[keep - 1][0]), flush=True)
+    if recheck:
+        fine = Objective(name, scene, ref8, 8, 1.0, variables)
+        cands = sorted(((fine(np.asarray(p)), p) for _f, p in cands[:recheck]), key=lambda c: c[0])
+        obj = fine
+        if verbose:
+            print("  recheck of %d at every 8th pixel: best %.5f, %d-th %.5f (%.0f s)" % (recheck, cands[0][0], keep, cands[min(keep, len(cands)) - 1][0], time.time() - t0), flush=True)
     # keep candidates that are not neighbours of a better one
     chosen = []
     span = hi - lo + 1e-9
