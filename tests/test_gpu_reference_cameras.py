@@ -27,6 +27,9 @@ def test_hip_path_equals_the_oracle_at_the_screenshot_s_camera(oracle, name):
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
     aspect = np.float32(W) / np.float32(H)
     f = oracle.default_frame(scene, W, H, basis=oracle.camera_direction(e["eye"], direction, fovy, aspect), stime=e["stime"])
+    slots = {row[0]: row[6] for row in oracle.var_table(scene)}
+    for k, v in e.get("variables", {}).items():  # sliders the screenshot was taken with (neon)
+        f.scene_var[slots[k]] = v
     ref, rst, tot = oracle.render(scene, f, stats=True)
     if e["scene"] == scene:
         assert int(tot[1]) == e["stats"]["rays"]  # the frame the statistics were taken on
@@ -34,6 +37,8 @@ def test_hip_path_equals_the_oracle_at_the_screenshot_s_camera(oracle, name):
     try:
         r.initShader(scene)
         r.setParameters(e["stime"])
+        for k, v in e.get("variables", {}).items():
+            assert r.setValue(k, v)
         cam = sp.Camera()
         cam.SetEye(e["eye"])
         cam.SetDirection(direction)

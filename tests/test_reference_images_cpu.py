@@ -10,7 +10,7 @@ statistics -- with the screenshots read where they lie (never copied; skipped wh
 What this pins that nothing else does: oracle/driver.h (ray generation, march, normal, shading, shadow / reflection /
 refraction rays, queue order), sdf_lib.h (primitives, operators, checker filter, sky), noise.h (the sky and the marble are
 simplex turbulence: a wrong permutation or gradient is a different cloud), postprocess.h (bloom, tone map) -- against pixels
-the reference's HLSL produced on its author's GPU.  Ten screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
+the reference's HLSL produced on its author's GPU.  Twelve screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
 (what is left there: the sky mirrored in cube tops, flame shapes, edge pixels shifted by a fraction of a pixel)."""
 import json
 import os
@@ -37,8 +37,8 @@ def test_oracle_reproduces_the_reference_s_screenshot(oracle, name):
     import fit_reference_images as fr
 
     e = FITS[name]
-    assert fr.TARGETS[name][0] == e["file"] and fr.TARGETS[name][1] == e["scene"]
-    stats, _ldr, _d = fr.compare(name, _params(e))
+    assert fr.TARGETS[name][0] == e["file"] and fr.TARGETS[name][1] == e["scene"] and fr.TARGETS[name][3] == e.get("variables", {})
+    stats, _ldr, _d = fr.compare(name, _params(e), variables=e.get("variables", {}))
     want = e["stats"]
     # the committed statistics are reproduced (same oracle, same screenshot) ...
     assert abs(stats["mean_abs_err"] - want["mean_abs_err"]) < 0.02 and abs(stats["within_3"] - want["within_3"]) < 0.003, (stats, want)
@@ -71,3 +71,18 @@ def test_a_camera_a_hundredth_off_is_noticed(oracle):
     p[0] += 0.01
     off, _l, _d = fr.compare("sphere", p)
     assert good["within_3"] > 0.999 and off["within_3"] < 0.99 and off["mean_abs_err"] > 5 * good["mean_abs_err"]
+
+
+def test_the_sliders_of_neon_png_sit_on_their_grid(oracle):
+    """Images/neon.png was taken with the glow's colour moved on the variable panel.  The three values that least squares finds are
+    recorded to two decimals; here: they lie on the sliders' grid (VAR_red / green / blue: step = 0.05, sdf_scene_neon.hlsl:43-45 --
+    the reference's VariableManager moves a slider in whole steps), and with the scene file's defaults the comparison fails loudly."""
+    import fit_reference_images as fr
+
+    e = FITS["neon"]
+    table = {row[0]: row for row in oracle.var_table("neon")}
+    for k, v in e["variables"].items():
+        step = table[k][4]
+        assert abs(v / step - round(v / step)) < 1e-3 and table[k][1] <= v <= table[k][2], (k, v)
+    defaults, _l, _d = fr.compare("neon", _params(e), variables={})
+    assert defaults["mean_abs_err"] > 10.0, defaults

@@ -46,6 +46,9 @@ TARGETS = {
     "transparency": ("transparency.png", "basic_transparency", None, {}),
     "shell": ("shell.png", "shell", None, {}),
     "distortion": ("distortion.png", "distortion", None, {}),
+    "gyroid": ("gyroid.png", "gyroid", None, {}),
+    # taken with three sliders moved (VariableManager): found by least squares, they sit on the sliders' 0.05 grid to three decimals
+    "neon": ("neon.png", "neon", None, {"red": 0.2, "green": 1.5, "blue": 2.05}),
     "sierpinski": ("sierpinski.png", "sierpinski", None, {}),
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
@@ -288,6 +291,8 @@ class FullObjective:
 def compare(name, p, variables=None, save=None):
     """Statistics of |oracle through HDR::process - screenshot| at the fitted parameters, on the full 1200 x 800 frame."""
     _file, scene, _g, _v = TARGETS[name]
+    if variables is None:
+        variables = _v
     ref8 = load_reference(name).astype(np.int32)
     ldr, hdr, totals = render_full(scene, p, variables)
     d = np.abs(ldr.astype(np.int32) - ref8).max(axis=2)  # per pixel: largest channel difference, in 1/255
