@@ -38,7 +38,11 @@ ARCH = "gfx950"
 _REV = ["-mllvm", "-greedy-reverse-local-assignment"]
 _MAXMEM = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
 _TOPDOWN = ["-mllvm", "-misched-prera-direction=topdown"]
-SCENE_FLAGS = {"SceneFractal": _REV, "SceneCoordinateMaterial": _REV, "SceneTerrain": _REV, "SceneTiling": _REV,
+_MAXILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# round 4 (tools/flag_search.py, gpurun_out/r04/s14): the fractal's 104-fma march loop draws 1 one-bank fma under max-ilp (4 under the reversed
+# local assignment it had, 15 by default): BASELINE configuration 4 1.044 / 1.048 -> 1.031 / 1.025 ms (-1.7 %), 20 bytes more scratch
+# outside the loop.  The same search left the labyrinth (default draw: rev +0.8 %, top-down +3 %), gems (+-0) and cube_sea where they were.
+SCENE_FLAGS = {"SceneFractal": _MAXILP, "SceneCoordinateMaterial": _REV, "SceneTerrain": _REV, "SceneTiling": _REV,
                "SceneCubeSea": _MAXMEM, "SceneShell": _MAXMEM, "SceneLense": _TOPDOWN}
 
 
@@ -48,13 +52,16 @@ def scene_registry():
     return [(int(i), n) for i, n in re.findall(r"X\((\d+), (Scene\w+)\)", text)]
 
 
-def group_flags(g):
-    """Options of compile unit g: those of the scenes in it (one scene per unit: SDFR_GROUPS >= scene count)."""
+def group_flags(g, override=None):
+    """Options of compile unit g: those of the scenes in it (one scene per unit: SDFR_GROUPS >= scene count).
+    override: {scene struct name: [flags]} replaces SCENE_FLAGS for those scenes (developer A/B of another register draw)."""
     groups = scene_groups()
     flags = []
+    table = dict(SCENE_FLAGS)
+    table.update(override or {})
     for i, name in scene_registry():
         if i % groups == g:
-            flags += [f for f in SCENE_FLAGS.get(name, []) if f not in flags or f == "-mllvm"]
+            flags += [f for f in table.get(name, []) if f not in flags or f == "-mllvm"]
     return flags
 
 
@@ -78,8 +85,9 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False, extra=(), out=None, jobs=None):
-    """Compile every HIP source for gfx950 into sdf_playground_amd/libsdfr.so (or `out`)."""
+def build(force=False, verbose=False, extra=(), out=None, jobs=None, scene_flags=None):
+    """Compile every HIP source for gfx950 into sdf_playground_amd/libsdfr.so (or `out`).
+    scene_flags: {scene struct name: [flags]} instead of SCENE_FLAGS for those scenes (only their units differ from the default build)."""
     if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -87,7 +95,10 @@ def build(force=False, verbose=False, extra=(), out=None, jobs=None):
     objdir = os.path.join(OBJDIR, hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else "default")
     os.makedirs(objdir, exist_ok=True)
     units = [(s, [], os.path.join(objdir, s + ".o")) for s in SOURCES]
-    units += [(GROUP_SOURCE, ["-DSDFR_GROUP=%d" % g] + group_flags(g), os.path.join(objdir, "%s.%d.o" % (GROUP_SOURCE, g))) for g in range(scene_groups())]
+    for g in range(scene_groups()):
+        flags = group_flags(g, scene_flags)
+        tag = "" if flags == group_flags(g) else "." + hashlib.sha1(" ".join(flags).encode()).hexdigest()[:8]
+        units.append((GROUP_SOURCE, ["-DSDFR_GROUP=%d" % g] + flags, os.path.join(objdir, "%s.%d%s.o" % (GROUP_SOURCE, g, tag))))
     newest_dep = max(os.path.getmtime(d) for d in _deps())
 
     def compile_unit(u):
