@@ -10,7 +10,7 @@ statistics -- with the screenshots read where they lie (never copied; skipped wh
 What this pins that nothing else does: oracle/driver.h (ray generation, march, normal, shading, shadow / reflection /
 refraction rays, queue order), sdf_lib.h (primitives, operators, checker filter, sky), noise.h (the sky and the marble are
 simplex turbulence: a wrong permutation or gradient is a different cloud), postprocess.h (bloom, tone map) -- against pixels
-the reference's HLSL produced on its author's GPU.  Thirteen screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
+the reference's HLSL produced on its author's GPU.  Fourteen screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
 (what is left there: the sky mirrored in cube tops, flame shapes, edge pixels shifted by a fraction of a pixel)."""
 import json
 import os

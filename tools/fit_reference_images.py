@@ -47,6 +47,7 @@ TARGETS = {
     "shell": ("shell.png", "shell", None, {}),
     "distortion": ("distortion.png", "distortion", None, {}),
     "gyroid": ("gyroid.png", "gyroid", None, {}),
+    "fractal": ("fractal.png", "fractal", None, {}),
     # two sliders moved: the cutting box pulled in (boxoffset 2 -> 1), the line threshold lowered (thres 0.4 -> 0.2); least squares: 0.99999697, 0.2023
     "coordinate-material": ("coordinate material.png", "coordinate_material", None, {"boxoffset": 1.0, "thres": 0.2}),
     # taken with three sliders moved (VariableManager): found by least squares, they sit on the sliders' 0.05 grid to three decimals
