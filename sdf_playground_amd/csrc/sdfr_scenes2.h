@@ -310,12 +310,19 @@ struct SceneDistortion
 		*valid = obj >= 0.05f;
 		return (obj - 0.026f) * 0.9999f;
 	}
+	// More than a bound: from obj = 0.0625 on the displaced distance IS `obj - h`, bit for bit.  distort() returns
+	// fma(t, b - a, a) with a = (obj - val) / 1.00125, b = obj - h, t = sat(obj / h - 1) = 1 (obj / h >= 2.5).  The pattern
+	// value is in [0, 0.025] (v in [0, 1], the turbulence in [-1, 1]: v * (0.8 + 0.2 n)), so b / 2 <= a <= 2 b
+	// (a <= obj / 1.00125 <= 2 obj - 0.05 from obj = 0.04994 on) and the subtraction b - a is exact (Sterbenz): the fma
+	// rounds the real number b, a float already.  Only the last step or two of a ray that reaches the wall evaluate the
+	// pattern.  Up to 1024 only: far beyond, the pattern's arguments overflow.  Bits compared in tests/test_scene_bounds_cpu.py.
+	static SDF_HD bool wall_is_plain_box(float obj) { return obj >= 0.0625f && obj <= 1024.f; }
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		bool valid;
-		const float lb = wall_lower_bound(p, &valid);
-		if (valid && lb >= d) return d;
+		const float obj = sd_box(p - V3(0.f, 1.5f, 0.f), V3(1.f, 1.f, 0.1f));
+		if (wall_is_plain_box(obj)) return min1(d, obj - 0.025f);
+		if (obj >= 0.05f && (obj - 0.026f) * 0.9999f >= d) return d;
 		return min1(d, wall(p).box);
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)

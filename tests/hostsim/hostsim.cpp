@@ -211,6 +211,9 @@ extern "C" long long hostsim_check_distortion_bounds(long long n, unsigned seed)
 		bool valid;
 		const float lb = SceneDistortion::wall_lower_bound(p, &valid);
 		if (valid && SceneDistortion::wall(p).box < lb) ++bad;
+		// ... and where the displaced distance is the plain box distance minus the height, bit for bit
+		const float obj = sd_box(p - V3(0.f, 1.5f, 0.f), V3(1.f, 1.f, 0.1f));
+		if (SceneDistortion::wall_is_plain_box(obj) && f32_bits(SceneDistortion::wall(p).box) != f32_bits(obj - 0.025f)) ++bad;
 	}
 	return bad;
 }

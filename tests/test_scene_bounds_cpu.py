@@ -75,7 +75,7 @@ def test_distortion_bound_holds_and_culling_is_invisible(oracle):
     L = hostsim.lib()
     L.hostsim_check_distortion_bounds.restype = ctypes.c_longlong
     L.hostsim_check_distortion_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint]
-    assert L.hostsim_check_distortion_bounds(600000, 3) == 0
+    assert L.hostsim_check_distortion_bounds(3000000, 3) == 0
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
     for eye, at in [((0.8, 1.8, -2.5), (0.0, 1.5, 0.0)), ((0.2, 1.5, -0.35), (0.0, 1.5, 0.0)), ((2.5, 0.3, 0.02), (0.0, 1.5, 0.0)), ((-3.0, 4.0, 3.0), (0.0, 1.0, 0.0))]:
         f = oracle.default_frame("distortion", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.4)
