@@ -381,13 +381,80 @@ SDF_HD void map_material(const FrameU &U, const DebugFlags &F, const SurfacePoin
 	}
 }
 
+// A scene may declare `static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)`: true only if
+// NOTHING of the scene lies on the ray from p onwards -- then the ray is a miss already (an escaped shadow ray delivers
+// its light, any other ray sees the background, whose colour does not depend on the step count in such a scene), and the
+// pixel kernel stops marching it (FrameU::step_shortcuts; never in the debug-plane build, whose plane is an extra object).
+template <class Scene, class = void>
+struct RayEscapes
+{
+	static constexpr bool available = false;
+	template <class R> static SDF_HD bool test(const FrameU &, const R &, vec3, vec3) { return false; }
+};
+template <class Scene>
+struct RayEscapes<Scene, typename VoidOfN<decltype(&Scene::ray_escapes)>::type>
+{
+	static constexpr bool available = true;
+	template <class R> static SDF_HD bool test(const FrameU &U, const R &r, vec3 p, vec3 dir) { return Scene::ray_escapes(U, r, p, dir); }
+};
+
+// A scene with ray_escapes may also declare `static constexpr bool inline_escaped_shadows = true`: a shadow ray that escapes where it
+// starts (no evaluation at all: two thirds of the rays of gems with eight lights, whose floor pixels send eight of them past the
+// ring) is then not queued -- a 48-byte record out and back, a turn of the bounce loop -- but delivers its light from the light
+// loop that made it, when that keeps the order of the pixel's sums: the queue is empty (it would be the next ray taken: smallest
+// depth, lowest slot), the hit's own colour has been added (shade_hit adds it before the lights' rays: InlineShadows::acc), and
+// the ray budget reaches it.  From the first ray that has to be queued on, the rest are queued as well.
+template <class Scene, class = void>
+struct InlineEscapedShadows { static constexpr bool value = false; };
+template <class Scene>
+struct InlineEscapedShadows<Scene, typename VoidOfN<decltype(Scene::inline_escaped_shadows)>::type>
+{
+	static constexpr bool value = Scene::inline_escaped_shadows && RayEscapes<Scene>::available;
+};
+struct InlineShadows
+{
+	vec3 acc;   // the pixel's sum; shade_hit adds the hit's colour and the delivered light to it, in the order the bounce loop would
+	int budget; // turns of the bounce loop left after this ray's
+	int taken;  // shadow rays delivered here: each counts as a ray and a turn
+};
+
+// light i of the frame: the scene's (its own slot function or the table a scene in the reference's shape filled), or an extension light
+template <class Scene, class Table, class Used>
+SDF_HD bool light_in_slot(const FrameU &U, int i, const Table &table, const Used &table_used, Light &L)
+{
+	bool used = SceneLightSlot<Scene>::get(U, i, L);
+	if (SceneLights<Scene>::available)
+	{
+		L = table[i];
+		used = table_used[i];
+	}
+	if (i >= 1 && i <= U.extension_lights) // extension: orbiting point lights (sdfr_frame.h)
+	{
+		const float *E = U.ext_light[i - 1];
+		L.pos = V3(E[0], E[1], E[2]);
+		L.directional = false;
+		L.extend = 0.25f;
+		L.falloff = 0.25f;
+		L.color = V3(E[3], E[4], E[5]);
+		used = true;
+	}
+	return used;
+}
+SDF_HD vec3 light_colour(const Light &L)
+{
+	float falloff = 1.f;
+	if (!L.directional) falloff = pow1(0.1f, L.falloff); // distance-independent (Q3)
+	return L.color * falloff;
+}
+
 // Shade a ray that hit the scene (pshader_sdf.hlsl:317-620).  Returns the colour this ray
 // adds to the pixel (already multiplied by the ray's contribution); updates `hdr`; pushes
 // secondary rays.
-template <class Scene, bool DBG, class Store>
+template <class Scene, bool DBG, class Store, bool INL = false>
 SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, const PixelRay &px, const HitInfo &hit, float max_range,
-	float &hdr, Spawner<Store> &q)
+	float &hdr, Spawner<Store> &q, InlineShadows *inl = nullptr)
 {
+	bool added = false; // INL: the returned colour is in inl->acc already
 	const uint32_t depth = ray_depth(ray);
 	const float inside_sign = ray_inside_sign(ray);
 	const vec3 view_dir = ray.dir;
@@ -539,6 +606,74 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 			vec3 lit_pos = mad(n, move, hit.pos);
 			const float alpha = sat1(m.diffuse.w);
 
+			if constexpr (INL)
+			{
+				// The hit's own colour first -- every light's ambient share, in the lights' order -- so that it is in the pixel's sum
+				// before any light a shadow ray delivers; then the loop as below, the ambient line left out.
+				for (int i = 0; i < U.light_count; ++i)
+				{
+					Light L;
+					if (!light_in_slot<Scene>(U, i, table, table_used, L)) continue;
+					color = color + diffuse * light_colour(L) * ambient;
+				}
+				color = color + m.emissive;
+				color = color * alpha;
+				out = out + color * ray.contrib;
+				inl->acc = inl->acc + out;
+				added = true;
+				for (int i = 0; i < U.light_count; ++i)
+				{
+					Light L;
+					if (!light_in_slot<Scene>(U, i, table, table_used, L)) continue;
+					vec3 ldir;
+					float trace_dist;
+					if (L.directional)
+					{
+						ldir = L.pos / (length(L.pos) + U.dist_eps);
+						trace_dist = U.range;
+					}
+					else
+					{
+						ldir = lit_pos - L.pos;
+						trace_dist = length(ldir);
+						ldir = ldir / trace_dist;
+						trace_dist = trace_dist - L.extend;
+					}
+					const vec3 lcol = light_colour(L);
+					float ndl = sat1(dot(-n, ldir));
+					vec3 direct = V3s(0.f) + diffuse * lcol * ndl;
+					vec3 half_vec = -normalize(view_dir + ldir);
+					float spec = pow1(sat1(dot(n, half_vec)), m.specular.w);
+					direct = direct + V3(m.specular.x, m.specular.y, m.specular.z) * lcol * spec;
+					if (depth + 2 < m.max_cost && ndl > 0.f)
+					{
+						RayRec c;
+						c.pos = lit_pos;
+						c.dir = -ldir;
+						c.contrib = direct * ray.contrib * alpha;
+						c.shadow_range = trace_dist;
+						c.bits = (depth + 2) | RAY_SHADOW;
+						// the reference's queue holds the rays delivered so far as well: it has a slot for this one only if all of them fit
+						if (inl->taken + q.count >= q.slots) continue;
+						if (U.step_shortcuts != 0 && q.count == 0 && inl->taken < inl->budget)
+						{
+							// the first turn of the march loop (render_pixel): an unrelaxed sample at the ray's start
+							const typename Scene::RayInv R = Scene::ray_setup(U, c.dir, ray_flags(c));
+							March sm = march_begin(c.pos, c.dir);
+							march_pre(sm);
+							if (sm.factor == 1.f && RayEscapes<Scene>::test(U, R, march_pos(sm), c.dir))
+							{
+								inl->acc = inl->acc + (V3s(0.f) + c.contrib); // shade_miss of a shadow ray
+								inl->taken++;
+								q.store.ray_marched(c, 0u, MARCH_MISS);
+								continue;
+							}
+						}
+						q.push(c);
+					}
+				}
+			}
+			else
 			for (int i = 0; i < U.light_count; ++i)
 			{
 				Light L;
@@ -597,10 +732,13 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 					q.push(c);
 				}
 			}
-			color = color + m.emissive;
-			color = color * alpha;
+			if (!added)
+			{
+				color = color + m.emissive;
+				color = color * alpha;
+			}
 		}
-		out = out + color * ray.contrib;
+		if (!added) out = out + color * ray.contrib;
 	}
 	else
 	{
@@ -616,6 +754,8 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 			q.push(c);
 		}
 	}
+	if constexpr (INL)
+		if (!added) inl->acc = inl->acc + out;
 	return out;
 }
 

@@ -110,23 +110,6 @@ struct RetireAfter { static constexpr int value = 8; };
 template <class Scene>
 struct RetireAfter<Scene, typename VoidOf<decltype(Scene::retire_after)>::type> { static constexpr int value = Scene::retire_after; };
 
-// A scene may declare `static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)`: true only if
-// NOTHING of the scene lies on the ray from p onwards -- then the ray is a miss already (an escaped shadow ray delivers
-// its light, any other ray sees the background, whose colour does not depend on the step count in such a scene), and the
-// pixel kernel stops marching it (FrameU::step_shortcuts; never in the debug-plane build, whose plane is an extra object).
-template <class Scene, class = void>
-struct RayEscapes
-{
-	static constexpr bool available = false;
-	template <class R> static SDF_HD bool test(const FrameU &, const R &, vec3, vec3) { return false; }
-};
-template <class Scene>
-struct RayEscapes<Scene, typename VoidOf<decltype(&Scene::ray_escapes)>::type>
-{
-	static constexpr bool available = true;
-	template <class R> static SDF_HD bool test(const FrameU &U, const R &r, vec3 p, vec3 dir) { return Scene::ray_escapes(U, r, p, dir); }
-};
-
 struct PixelCounters
 {
 	uint32_t rays, march_evals, hits;
@@ -150,6 +133,7 @@ template <class Scene, bool DBG, class Store>
 SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, Store &store)
 {
 	SDFR_CLK(c_begin);
+	constexpr bool INL = !DBG && InlineEscapedShadows<Scene>::value;
 	const DebugFlags F = debug_flags(U);
 	RayRec ray;
 	{
@@ -277,7 +261,20 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 
 			Spawner<Store> q(store, depths, count, U.ray_count);
 			float hdr = store.hdr_kept();
-			out = shade_hit<Scene, DBG, Store>(U, F, ray, store.pixel_ray_kept(), hit, max_range, hdr, q);
+			if constexpr (INL)
+			{
+				// escaped shadow rays deliver their light from the light loop (InlineEscapedShadows, sdfr_pixel.h): each is a ray and a turn of this loop
+				InlineShadows inl;
+				inl.acc = acc;
+				inl.budget = U.bounce_count - 1 - bounce;
+				inl.taken = 0;
+				out = shade_hit<Scene, DBG, Store, true>(U, F, ray, store.pixel_ray_kept(), hit, max_range, hdr, q, &inl);
+				acc = inl.acc;
+				bounce += inl.taken;
+				cnt.rays += (uint32_t)inl.taken;
+			}
+			else
+				out = shade_hit<Scene, DBG, Store>(U, F, ray, store.pixel_ray_kept(), hit, max_range, hdr, q);
 			store.keep_hdr(hdr);
 			depths = q.depths;
 			count = q.count;
@@ -286,6 +283,7 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 #endif
 			SDFR_CLK(c3);
 			SDFR_CLK_ADD(clk_shade, c2, c3);
+			if constexpr (!INL) acc = acc + out;
 		}
 		else
 		{
@@ -295,8 +293,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 #endif
 			SDFR_CLK(c4);
 			SDFR_CLK_ADD(clk_miss, c1, c4);
+			acc = acc + out;
 		}
-		acc = acc + out;
 	}
 	SDFR_CLK(c_end);
 	SDFR_CLK_ADD(clk_total, c_begin, c_end);

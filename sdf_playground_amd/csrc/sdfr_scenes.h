@@ -624,6 +624,7 @@ struct SceneGems
 	static constexpr int retire_after = 1; // configuration 5g with tile rows 1.74 (8) / 1.68 (2) / 1.71 (1) ms, with the squares 1.480 (1) / 1.505 (2) / 1.510 (3) / 1.562 (4) / 1.81 (8) (profiles/r03_launch_experiments.txt)
 	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
+	static constexpr bool inline_escaped_shadows = true; // a floor pixel's shadow rays pass the ring at a distance (sdfr_pixel.h)
 	static const char *variables() { return ""; }
 	enum { SU_ROT_S = 0, SU_ROT_C = 1 };
 	static SDF_HD void prepare(FrameU &U)

@@ -85,3 +85,23 @@ def test_camera_under_the_floor_matches_the_oracle_with_shortcuts(oracle, scene)
     img, st = hostsim.render(scene, hf)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2])
+
+
+@pytest.mark.parametrize("bounces,slots", [(16, 8), (9, 8), (5, 8), (3, 8), (2, 8), (1, 8), (16, 4), (16, 1), (6, 3)])
+def test_shadow_rays_delivered_from_the_light_loop_keep_budget_and_order(oracle, bounces, slots):
+    """gems declares inline_escaped_shadows (sdfr_pixel.h): a floor pixel's escaped shadow rays never enter the queue.  With eight
+    lights, a ray budget that ends among them and a queue shorter than their number, pixels, ray and hit counts stay the oracle's."""
+    import hostsim
+
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for eye, at in [((2.5, 2.0, 0.5), (0.0, 1.0, 0.0)), ((0.3, 0.4, -4.0), (0.0, 0.8, 0.0)), ((5.0, 6.0, 5.0), (0.0, 0.0, 0.0))]:
+        f = oracle.default_frame("gems", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=1.3)
+        f.max_cost_default, f.extension_lights = 9, 7
+        f.bounce_count, f.ray_count = bounces, slots
+        ref, rst, _ = oracle.render("gems", f, stats=True)
+        hf = hostsim.frame_from_oracle(f)
+        hf.step_shortcuts = 1
+        img, st = hostsim.render("gems", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, bounces, slots)
+        assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]), (eye, bounces, slots)
+        assert bounces < 3 or (st[..., 1] < rst[..., 1]).any()  # the rule fired: fewer evaluations than the reference makes
