@@ -37,6 +37,7 @@ struct SceneFastSphere
 	}
 	// floor + one sphere of radius 0.5 about (0, 1, 0)
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.51f, V3(0.f, 1.f, 0.f), 0.52f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3 dir, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -345,6 +346,7 @@ struct SceneFractal
 	}
 	// every box lies in the unit ball about (0, 1, 0) (see dist): nothing above y = 2, and the floor is behind a ray that does not descend
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	// 8-level recursive fold; returns the distance, and the level that first touched
 	static SDF_HD float fold(vec3 p, float *level_hit)
 	{

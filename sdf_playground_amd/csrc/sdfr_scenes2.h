@@ -40,6 +40,7 @@ struct SceneCube
 		const vec3 c = V3(U.scene_var[V_X], 1.f + U.scene_var[V_Y], U.scene_var[V_Z]);
 		return ray_leaves_floor_and_ball(p, dir, c.y + size * 1.001f + 0.01f, c, size * 1.7330f + 0.02f);
 	}
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -115,6 +116,7 @@ struct SceneBasicTransparency
 	// floor + three panes of half size (1, 1, 0.1) about (0, 2, -1 / 0 / 1): below y = 3, inside the ball of radius
 	// sqrt(1 + 1 + 1.1^2) = 1.79 about (0, 2, 0)
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 3.01f, V3(0.f, 2.f, 0.f), 1.82f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -215,6 +217,7 @@ struct SceneCoordinateMaterial
 	}
 	// floor + a sphere of radius 2 about (0, 2, 0) with a box cut out of it (max(sphere, -box) >= sphere)
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 4.01f, V3(0.f, 2.f, 0.f), 2.02f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -274,6 +277,7 @@ struct SceneDistortion
 	// A ray that does not descend (the floor is behind it) and is above that height, or whose line passes that ball at a
 	// distance or has it behind, has nothing left to hit.
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.6f, V3(0.f, 1.5f, 0.f), 1.5f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	// displace a distance field by a height function with known Lipschitz bound
 	static SDF_HD float distort(float obj, float val, float lip, float h)
 	{
@@ -385,6 +389,7 @@ struct SceneTable
 	// (within 0.22 of the axis, cut off at y = 1.715: vase >= cut_top) lie below y = 1.72 and in the ball of radius 1.80
 	// about (0, 0.7, 0) (plate corner and leg foot are its farthest points).
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 1.73f, V3(0.f, 0.7f, 0.f), 1.85f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
@@ -457,6 +462,7 @@ struct SceneSierpinski
 	// 2 |p| - 1, so |p_k| - 1 >= 2^k (|p| - 1) and tetra(p) >= |p| - 1.001: the gasket lies in the ball of radius 1.001
 	// about (0, 1, 0), below y = 2.001.
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.01f, V3(0.f, 1.f, 0.f), 1.02f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
