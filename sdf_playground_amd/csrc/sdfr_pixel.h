@@ -398,6 +398,22 @@ struct RayEscapes<Scene, typename VoidOfN<decltype(&Scene::ray_escapes)>::type>
 	template <class R> static SDF_HD bool test(const FrameU &U, const R &r, vec3 p, vec3 dir) { return Scene::ray_escapes(U, r, p, dir); }
 };
 
+// ... and / or `static SDF_HD float escapes_from(const FrameU &U, vec3 start, vec3 dir, float range)`, worked out once per ray: the
+// distance along the ray from which on nothing of the scene lies between the march and `range`, where it declares the ray out of
+// range (a shadow ray towards a point light ends there; samples beyond are misses whatever they measure) -- 3e38 if there is no such
+// distance.  A sample beyond it is a miss as well; one comparison per step.
+template <class Scene, class = void>
+struct EscapesFrom
+{
+	static constexpr bool available = false;
+	static SDF_HD float get(const FrameU &, vec3, vec3, float) { return 3e38f; }
+};
+template <class Scene>
+struct EscapesFrom<Scene, typename VoidOfN<decltype(&Scene::escapes_from)>::type>
+{
+	static constexpr bool available = true;
+	static SDF_HD float get(const FrameU &U, vec3 start, vec3 dir, float range) { return Scene::escapes_from(U, start, dir, range); }
+};
 // A scene with ray_escapes may also declare `static constexpr bool inline_escaped_shadows = true`: a shadow ray that escapes where it
 // starts (no evaluation at all: two thirds of the rays of gems with eight lights, whose floor pixels send eight of them past the
 // ring) is then not queued -- a 48-byte record out and back, a turn of the bounce loop -- but delivers its light from the light

@@ -166,7 +166,10 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 		March m = march_begin(ray.pos, ray.dir);
 		int status;
 		const uint32_t evals_before = cnt.march_evals;
-		const bool shortcuts = !DBG && RayEscapes<Scene>::available && U.step_shortcuts != 0 && inside_sign > 0.f; // (a ray inside a refracting body ends on its surface)
+		const bool shortcuts = !DBG && (RayEscapes<Scene>::available || EscapesFrom<Scene>::available) && U.step_shortcuts != 0 && inside_sign > 0.f;
+		float clear_from = 3e38f;
+		if constexpr (EscapesFrom<Scene>::available)
+			if (shortcuts) clear_from = EscapesFrom<Scene>::get(U, ray.pos, ray.dir, max_range); // (a ray inside a refracting body ends on its surface)
 		do
 		{
 			march_pre(m);
@@ -174,7 +177,8 @@ SDF_HD vec4 render_pixel(const FrameU &U, int px, int py, PixelCounters &cnt, St
 			// first three samples and everything after a rewind) is final as it stands, a relaxed one once its own distance
 			// shows that it did not over-step (march_advance's test) -- an over-stepped sample can lie beyond an obstacle
 			// that the rewound march then hits.
-			const bool escaped = shortcuts && RayEscapes<Scene>::test(U, R, march_pos(m), ray.dir);
+			bool escaped = shortcuts && RayEscapes<Scene>::test(U, R, march_pos(m), ray.dir);
+			if constexpr (EscapesFrom<Scene>::available) escaped = escaped || m.t >= clear_from;
 			if (escaped && m.factor == 1.f)
 			{
 				status = MARCH_MISS; // what the remaining steps would come to

@@ -505,6 +505,31 @@ struct SceneLense
 		const float k = max1(d, 0.f) + (radius + 0.01f);
 		return dot(v, v) >= k * k;
 	}
+	// Between the two blob fields (blob >= |h| - 1.11: nothing of them where |y| < 3.88) lie only the lens (in the ball of radius 2 about
+	// the origin), the light ball (radius 2) and the pane with its frame (in the ball of radius 2.38 about (0, 0, -5)).  What a ray has
+	// left to go -- a shadow ray ends at its light, and the extension lights hang 3 high -- meets nothing once it is in that slab for
+	// good (it ends there, and has crossed |y| = 3.86 if it started outside) and has each ball behind it or passes it at a distance:
+	// the distance along the ray from which that holds.  0.01 - 0.02 of slack for rounding (dir is a unit vector to 1e-7); NaN or an
+	// end outside the slab: never.
+	static SDF_HD float ball_left_behind(vec3 start, vec3 dir, vec3 c, float radius)
+	{
+		const vec3 v = start - c;
+		const float b = dot(v, dir), cc = dot(v, v) - radius * radius;
+		const float disc = b * b - cc;
+		if (disc < 0.f) return 0.f; // the line passes at a distance
+		return (sqrt1(disc) - b) + 0.01f; // the far intersection (NaN stays NaN)
+	}
+	static SDF_HD float escapes_from(const FrameU &U, vec3 start, vec3 dir, float range)
+	{
+		const float y_end = start.y + dir.y * range;
+		if (!(abs1(y_end) < 3.86f)) return 3e38f;
+		float t = 0.f;
+		if (!(abs1(start.y) < 3.86f)) t = ((start.y > 0.f ? 3.86f : -3.86f) - start.y) / dir.y; // y(t) = +-3.86: from there to the end inside the slab
+		const vec3 ball = V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]);
+		const float t0 = ball_left_behind(start, dir, V3(0.f, 0.f, 0.f), 2.02f), t1 = ball_left_behind(start, dir, ball, 2.02f), t2 = ball_left_behind(start, dir, V3(0.f, 0.f, -5.f), 2.40f);
+		t = max1(max1(t, t0), max1(t1, t2));
+		return (t == t && t0 == t0 && t1 == t1 && t2 == t2) ? t : 3e38f;
+	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool)
 	{
 		// min() over the same objects as map(), any order gives the same bits.  Which order is cheap depends on where the

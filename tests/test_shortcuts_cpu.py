@@ -105,3 +105,27 @@ def test_shadow_rays_delivered_from_the_light_loop_keep_budget_and_order(oracle,
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, bounces, slots)
         assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]), (eye, bounces, slots)
         assert bounces < 3 or (st[..., 1] < rst[..., 1]).any()  # the rule fired: fewer evaluations than the reference makes
+
+
+@pytest.mark.parametrize("ball", [None, (3.0, 1.5, 4.0), (-4.0, -3.0, 0.5), (0.0, 0.0, 25.0)])
+def test_lense_shadow_rays_end_between_the_blob_fields(oracle, ball):
+    """lense declares escapes_from (sdfr_pixel.h): a shadow ray towards an extension light (3 high, between the blob fields) is a miss
+    once it is inside the free slab and has lens, light ball and pane behind it or aside.  Pixels, rays and hits stay the oracle's
+    wherever the light ball is moved."""
+    import hostsim
+
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    fired = False
+    for eye, at in [((0.0, 0.5, 7.0), (0.0, 0.0, 0.0)), ((6.0, -2.0, -6.0), (0.0, -4.0, 0.0)), ((1.0, 3.0, 1.0), (0.0, 5.0, -5.0)), ((0.2, 0.1, 0.3), (0.0, 0.0, -5.0))]:
+        f = oracle.default_frame("lense", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=2.1)
+        f.max_cost_default, f.extension_lights, f.bounce_count = 9, 7, 16
+        if ball is not None:
+            f.scene_var[0], f.scene_var[1], f.scene_var[2] = ball
+        ref, rst, _ = oracle.render("lense", f, stats=True)
+        hf = hostsim.frame_from_oracle(f)
+        hf.step_shortcuts = 1
+        img, st = hostsim.render("lense", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, ball)
+        assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]), (eye, ball)
+        fired = fired or bool((st[..., 1] < rst[..., 1]).any())
+    assert fired
