@@ -10,7 +10,7 @@ statistics -- with the screenshots read where they lie (never copied; skipped wh
 What this pins that nothing else does: oracle/driver.h (ray generation, march, normal, shading, shadow / reflection /
 refraction rays, queue order), sdf_lib.h (primitives, operators, checker filter, sky), noise.h (the sky and the marble are
 simplex turbulence: a wrong permutation or gradient is a different cloud), postprocess.h (bloom, tone map) -- against pixels
-the reference's HLSL produced on its author's GPU.  Fourteen screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
+the reference's HLSL produced on its author's GPU.  Fifteen screenshots; the worst of them has 92 % of ALL pixels within 3 / 255
 (what is left there: the sky mirrored in cube tops, flame shapes, edge pixels shifted by a fraction of a pixel)."""
 import json
 import os
@@ -38,6 +38,7 @@ def test_oracle_reproduces_the_reference_s_screenshot(oracle, name):
 
     e = FITS[name]
     assert fr.TARGETS[name][0] == e["file"] and fr.TARGETS[name][1] == e["scene"] and fr.TARGETS[name][3] == e.get("variables", {})
+    assert fr.ROWS_FROM.get(name, 0) == e.get("rows_from", 0)  # (spiral.png: from the horizon down, its sky is an older one)
     stats, _ldr, _d = fr.compare(name, _params(e), variables=e.get("variables", {}))
     want = e["stats"]
     # the committed statistics are reproduced (same oracle, same screenshot) ...
