@@ -649,7 +649,7 @@ struct SceneGems
 	static constexpr bool square_units = true; // the gems in the middle of the picture: with 8 lights and depth 4 their tiles render for 0.9 ms; first, not last: configuration 5g 1.657 -> 1.563 ms
 	static constexpr bool persistent_tiles = true; // with 8 lights and depth 4 (configuration 5g) 2.88 -> 2.80 ms; the plain scene 1.10 -> 1.09
 	static constexpr int retire_after = 1; // configuration 5g with tile rows 1.74 (8) / 1.68 (2) / 1.71 (1) ms, with the squares 1.480 (1) / 1.505 (2) / 1.510 (3) / 1.562 (4) / 1.81 (8) (profiles/r03_launch_experiments.txt)
-	static constexpr int waves_per_simd = 5; // configuration 5g 2.757 -> 2.720 ms (sdfr_pixel_kernel.h)
+	static constexpr int waves_per_simd = 7; // configuration 5g, with its escaped shadow rays delivered: 1.368 (5) / 1.336 (6) / 1.336 (7) / 1.536 (8) ms; the plain scene 0.799 / 0.818 / 0.779 / 0.873 (sdfr_pixel_kernel.h)
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static constexpr bool inline_escaped_shadows = true; // a floor pixel's shadow rays pass the ring at a distance (sdfr_pixel.h)
 	static const char *variables() { return ""; }
