@@ -17,7 +17,7 @@ import sdf_playground_amd as sp
 from oracle import pyoracle as po
 
 
-def run(cases, seed, size, scenes=None, verbose=False):
+def run(cases, seed, size, scenes=None, verbose=False, shortcut_heavy=False):
     rng = np.random.default_rng(seed)
     W, H = size
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
@@ -68,9 +68,13 @@ def run(cases, seed, size, scenes=None, verbose=False):
                     f.scene_var[slot] = v
                     r.setValue(name, v)
             schedule = int(rng.integers(0, 2))
+            if shortcut_heavy:  # the pixel schedule with step shortcuts on, eight lights in half of the cases: what the escape rules and the delivered shadow rays see
+                schedule = 1
+                f.extension_lights = limits["extension_lights"] = int(rng.choice([0, 7]))
+                r.setLimits(**limits)
             r.setSchedule(schedule)
             r.setLaunchMode(int(rng.choice([sp.LAUNCH_AUTO, sp.LAUNCH_PER_TILE, sp.LAUNCH_PERSISTENT])))  # pixel schedule: how the tiles reach the waves
-            shortcuts = bool(rng.integers(0, 2)) and schedule == 1  # step shortcuts: same pixels, rays and hits; fewer steps counted
+            shortcuts = (bool(rng.integers(0, 2)) or shortcut_heavy) and schedule == 1  # step shortcuts: same pixels, rays and hits; fewer steps counted
             r.setStepShortcuts(shortcuts)
             img, st = r.render(cam, W, H, pixel_stats=True)
             ref, rst, _ = po.render(scene, f, stats=True)
@@ -97,8 +101,9 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--size", default="64x48")
     ap.add_argument("--scenes", default="")
+    ap.add_argument("--shortcut-heavy", action="store_true", help="every case on the pixel schedule with step shortcuts, half of them with eight lights")
     a = ap.parse_args()
     w, h = (int(x) for x in a.size.split("x"))
-    n, bad = run(a.cases, a.seed, (w, h), [s for s in a.scenes.split(",") if s] or None)
+    n, bad = run(a.cases, a.seed, (w, h), [s for s in a.scenes.split(",") if s] or None, shortcut_heavy=a.shortcut_heavy)
     print("%d cases, %d mismatches" % (n, len(bad)))
     sys.exit(1 if bad else 0)
