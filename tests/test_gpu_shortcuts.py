@@ -184,3 +184,50 @@ def test_run_time_scene_with_an_escape_rule(renderer, oracle):
             assert np.array_equal(st[..., 1], rst[..., 1]) if not on else (st[..., 1] <= rst[..., 1]).all()
     finally:
         renderer.setStepShortcuts(False)
+
+
+@pytest.mark.parametrize("bounces,slots", [(16, 8), (9, 8), (5, 8), (3, 8), (2, 8), (1, 8), (16, 4), (16, 1), (6, 3)])
+def test_delivered_shadow_rays_keep_budget_and_queue_length(renderer, oracle, bounces, slots):
+    """gems declares inline_escaped_shadows: with eight lights, a ray budget that ends among a floor pixel's shadow rays and a queue
+    shorter than their number, the HIP path renders the oracle's pixels, ray and hit counts (the CPU tier runs the same cases on
+    the host build: tests/test_shortcuts_cpu.py)."""
+    renderer.initShader("gems")
+    limits = dict(max_cost_default=9, extension_lights=7, bounce_count=bounces, ray_count=slots)
+    try:
+        for k, (eye, at) in enumerate([((2.5, 2.0, 0.5), (0.0, 1.0, 0.0)), ((0.3, 0.4, -4.0), (0.0, 0.8, 0.0)), ((5.0, 6.0, 5.0), (0.0, 0.0, 0.0))]):
+            f, img, st, _tot = _render(renderer, oracle, "gems", eye, at, 160, 96, 1.3 + k, limits, True)
+            ref, rst, _ = oracle.render("gems", f, stats=True)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, bounces, slots)
+            assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2])
+            assert (st[..., 1] <= rst[..., 1]).all()
+    finally:
+        renderer.setStepShortcuts(False)
+        renderer.setLimits(max_cost_default=7, extension_lights=0, bounce_count=16, ray_count=8)
+
+
+@pytest.mark.parametrize("ball", [None, (3.0, 1.5, 4.0), (-4.0, -3.0, 0.5), (0.0, 0.0, 25.0)])
+def test_lense_shadow_rays_end_between_the_blob_fields(renderer, oracle, ball):
+    """lense declares escapes_from: shadow rays towards the extension lights end between the blob fields, wherever the light ball is"""
+    renderer.initShader("lense")
+    limits = dict(max_cost_default=9, extension_lights=7)
+    saved = 0
+    try:
+        renderer.resetVariables()
+        if ball is not None:
+            for name, v in zip(("xpos", "ypos", "zpos"), ball):
+                renderer.setValue(name, v)
+        for eye, at in [((0.0, 0.5, 7.0), (0.0, 0.0, 0.0)), ((6.0, -2.0, -6.0), (0.0, -4.0, 0.0)), ((1.0, 3.0, 1.0), (0.0, 5.0, -5.0))]:
+            fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+            f, img, st, _tot = _render(renderer, oracle, "lense", eye, at, 160, 96, 2.1, limits, True)
+            if ball is not None:
+                f.scene_var[0], f.scene_var[1], f.scene_var[2] = ball
+            ref, rst, _ = oracle.render("lense", f, stats=True)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, ball)
+            assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2])
+            assert (st[..., 1] <= rst[..., 1]).all()
+            saved += int(rst[..., 1].sum()) - int(st[..., 1].sum())
+        assert saved > 0
+    finally:
+        renderer.setStepShortcuts(False)
+        renderer.resetVariables()
+        renderer.setLimits(max_cost_default=7, extension_lights=0)
