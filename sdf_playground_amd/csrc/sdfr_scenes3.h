@@ -236,6 +236,8 @@ struct SceneTerrain
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)
 	{
 		if (R.rising && p.y > 5.01f) return true;
+		// ... or beyond any other face of the box and not coming back (shape() >= the box's distance >= |p_i| - 5 on every axis)
+		if ((abs1(p.x) > 5.01f && p.x * dir.x >= 0.f) || (abs1(p.z) > 5.01f && p.z * dir.z >= 0.f) || (p.y < -5.01f && dir.y <= 0.f)) return true;
 		const float b = dot(p, dir), vv = dot(p, p);
 		return vv > 8.7f * 8.7f && (b >= 0.f || vv - b * b > 8.7f * 8.7f);
 	}
