@@ -235,7 +235,11 @@ struct SceneTerrain
 	// 8.7) at a distance, or has it behind, is gone whichever way it points.
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir)
 	{
-		if (R.rising && p.y > 5.01f) return true;
+		// ... and the terrain itself ends far below the box's lid: an octave lowers the running distance by 0.175 s at most (smax(n, d - 0.1 s)
+		// is >= d - 0.1 s, and the polynomial smin() stays within a quarter of its 0.3 s below the smaller operand), so fbm(p, p.y) >=
+		// p.y - 0.175 (1 + 1/2 + 1/4 + ...) = p.y - 0.35 whatever the number of levels: nothing above y = 0.35, and a ray that
+		// does not descend is gone from 0.37 on (0.02 above it: dist_eps is 1e-3 at most).  Checked numerically in tests/test_scene_bounds_cpu.py.
+		if (R.rising && p.y > 0.37f) return true;
 		// ... or beyond any other face of the box and not coming back (shape() >= the box's distance >= |p_i| - 5 on every axis)
 		if ((abs1(p.x) > 5.01f && p.x * dir.x >= 0.f) || (abs1(p.z) > 5.01f && p.z * dir.z >= 0.f) || (p.y < -5.01f && dir.y <= 0.f)) return true;
 		const float b = dot(p, dir), vv = dot(p, p);

@@ -343,6 +343,33 @@ extern "C" long long hostsim_check_gems_bound(long long n, unsigned seed, double
 	return bad;
 }
 
+// the terrain's height: fbm(p, p.y) >= p.y - 0.35 for every number of levels (SceneTerrain::ray_escapes: nothing above y = 0.35)
+extern "C" long long hostsim_check_terrain_height(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 909ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	FrameU U;
+	frame_defaults(U);
+	SceneTerrain::prepare(U);
+	for (long long i = 0; i < n; ++i)
+	{
+		U.scene_var[0] = (float)(1 + (int)(rnd() * 10.f)); // levels 1 .. 10
+		// mostly around the surface and the lid of the rule, some far away
+		const float span = (i % 4 == 3) ? 300.f : 6.f;
+		const vec3 p = V3((rnd() * 2.f - 1.f) * span, (i % 4 == 3) ? (rnd() * 2.f - 1.f) * 50.f : -0.5f + rnd() * 1.5f, (rnd() * 2.f - 1.f) * span);
+		const float f = SceneTerrain::fbm(U, p, p.y);
+		if (!(f >= p.y - 0.35f)) ++bad;
+		if ((double)f - ((double)p.y - 0.35) < slack) slack = (double)f - ((double)p.y - 0.35);
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
 // the tree scene's lattice (sdfr_scenes4.h): border_lower_bound() never exceeds lattice_border(), whatever the
 // position (small, large, on cell borders) and the direction (unit, axis-parallel, degenerate)
 extern "C" long long hostsim_check_tree_border_bound(long long n, unsigned seed, double *min_slack)

@@ -140,6 +140,11 @@ def test_terrain_octave_skip_is_invisible(oracle):
     L.hostsim_check_terrain_octave_skip.restype = ctypes.c_longlong
     L.hostsim_check_terrain_octave_skip.argtypes = [ctypes.c_longlong, ctypes.c_uint]
     assert L.hostsim_check_terrain_octave_skip(2000000, 17) == 0
+    L.hostsim_check_terrain_height.restype = ctypes.c_longlong
+    L.hostsim_check_terrain_height.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_terrain_height(3000000, 23, ctypes.byref(slack)) == 0  # fbm(p, p.y) >= p.y - 0.35: nothing above y = 0.35
+    assert slack.value > 0.05
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
     views = [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((0.0, 9.0, -14.0), (0.0, 0.0, 0.0)), ((3.0, 0.7, 3.0), (-2.0, 0.4, -1.0)), ((0.5, 30.0, 0.5), (0.4, 0.0, 0.6)),
              ((12.0, 1.0, 0.0), (0.0, 0.5, 0.0)), ((2.0, 2000.0, 2.0), (0.0, 0.0, 0.0))]
