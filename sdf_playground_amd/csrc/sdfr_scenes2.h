@@ -69,14 +69,25 @@ struct SceneGyroid
 	static SDF_HD void prepare(FrameU &) {}
 	struct RayInv { int unused; };
 	static SDF_HD RayInv ray_setup(const FrameU &U, vec3, const RayFlags &) { RayInv r; r.unused = 0; return r; }
-	// a gyroid shell clipped to the unit cube; no floor in this scene
+	// shape() = max(gyroid, cube) >= the cube's distance, and the scene has nothing else (no floor): a ray beyond a face of the cube
+	// that does not come back, or whose line passes the cube's ball (radius sqrt(3) = 1.733; 1.75) at a distance, has left it
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir)
+	{
+		if ((abs1(p.x) > 1.01f && p.x * dir.x >= 0.f) || (abs1(p.y) > 1.01f && p.y * dir.y >= 0.f) || (abs1(p.z) > 1.01f && p.z * dir.z >= 0.f)) return true;
+		const float b = dot(p, dir), vv = dot(p, p);
+		return vv > 1.75f * 1.75f && (b >= 0.f || vv - b * b > 1.75f * 1.75f);
+	}
+	// a gyroid shell clipped to the unit cube; no floor in this scene.  The shell's term is |sin x cos z + sin y cos x + sin z cos y| / 14
+	// - 0.01 <= 3 / 14 - 0.01 = 0.2043: from 0.22 off the cube max() returns the cube's distance, and the three sincos are left out.
 	static SDF_HD float shape(vec3 p)
 	{
+		const float box = sd_box(p, V3(1.f, 1.f, 1.f));
+		if (box >= 0.22f) return box;
 		const vec3 q = p * 7.f;
 		const vec2 sx = sincos1(q.x), sy = sincos1(q.y), sz = sincos1(q.z);
 		float g = dot(V3(sx.x, sy.x, sz.x), V3(sz.y, sx.y, sy.y)) / 14.f;
 		g = abs1(g) - 0.01f;
-		return max1(g, sd_box(p, V3(1.f, 1.f, 1.f)));
+		return max1(g, box);
 	}
 	static SDF_HD float dist(const FrameU &U, const RayInv &, vec3 p, vec3, bool) { return min1(3e38f, shape(p)); }
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)

@@ -47,10 +47,20 @@ struct SceneFractal2
 		const float reduced = (v - lower) / range;
 		return (reduced - floor1(reduced)) * range + lower;
 	}
+	// Every box lies in the ball of radius 1.21 about (0, 1, 0): between two levels the point is folded (abs, sort: lengths kept), moved by
+	// (-1/3, -0.3337) and then by 1/3 along an axis -- 0.472 + 0.333 = 0.805 at most -- and scaled by 3, so a point inside a box of level
+	// i (|q_i| <= 0.866) has |q_(i-1)| <= |q_i| / 3 + 0.805: 1.094, 1.17, 1.195, ... < 1.2075.  fold() is a min() over exact box distances,
+	// so it is >= |p - c| - 1.21: skipped where that is not below the floor's distance, and a ray that leaves the ball and the floor is a miss
+	// (0.02 of slack; checked numerically in tests/test_scene_bounds_cpu.py).
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.24f, V3(0.f, 1.f, 0.f), 1.23f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		return min1(d, fold(p - V3(0.f, 1.f, 0.f)));
+		const vec3 v = p - V3(0.f, 1.f, 0.f);
+		const float k = max1(d, 0.f) + 1.23f;
+		if (dot(v, v) >= k * k) return d;
+		return min1(d, fold(v));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

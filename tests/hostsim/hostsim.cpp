@@ -194,6 +194,40 @@ extern "C" long long hostsim_check_fractal_bounds(long long n, unsigned seed)
 	return bad;
 }
 
+// fractal2's bounding ball (sdfr_scenes3.h: 1.21 about the fold's centre) and the gyroid's exact cull (sdfr_scenes2.h: from 0.22 off
+// its cube shape() is the cube's distance, bit for bit)
+extern "C" long long hostsim_check_fractal2_gyroid_bounds(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 1212ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	for (long long i = 0; i < n; ++i)
+	{
+		const float r = (i & 1) ? 0.9f + rnd() * 0.6f : rnd() * 6.f;
+		vec3 v = V3(rnd() * 2.f - 1.f, rnd() * 2.f - 1.f, rnd() * 2.f - 1.f);
+		const float len = length(v);
+		if (len < 1e-3f) continue;
+		v = v * (r / len);
+		const float d = SceneFractal2::fold(v);
+		if (!(d >= (r - 1.21f) - 1e-5f)) ++bad;
+		if ((double)d - ((double)r - 1.21) < slack) slack = (double)d - ((double)r - 1.21);
+		// the gyroid: points around its cube, some far away
+		const vec3 g = (i % 5 == 4) ? v * 50.f : v * 1.2f;
+		const float box = sd_box(g, V3(1.f, 1.f, 1.f));
+		const vec3 q = g * 7.f;
+		const vec2 sx = sincos1(q.x), sy = sincos1(q.y), sz = sincos1(q.z);
+		const float shell = abs1(dot(V3(sx.x, sy.x, sz.x), V3(sz.y, sx.y, sy.y)) / 14.f) - 0.01f;
+		if (f32_bits(SceneGyroid::shape(g)) != f32_bits(max1(shell, box))) ++bad;
+		if (!(shell <= 0.2045f)) ++bad;
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
 // the distortion scene's lower bound of the displaced wall (sdfr_scenes2.h)
 extern "C" long long hostsim_check_distortion_bounds(long long n, unsigned seed)
 {

@@ -224,3 +224,30 @@ def test_gems_bound_holds_and_culling_is_invisible(oracle):
         img, st = hostsim.render("gems", hostsim.frame_from_oracle(f))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, at)
         assert np.array_equal(st, rst)
+
+
+def test_fractal2_ball_and_gyroid_cull(oracle):
+    """fractal2's boxes lie in the ball of radius 1.21 about the fold's centre (its escape rule and the cull of its fold), and the
+    gyroid's shape() is its cube's distance from 0.22 off the cube, bit for bit; frames from outside, inside and far away keep their bits"""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_fractal2_gyroid_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_fractal2_gyroid_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_fractal2_gyroid_bounds(4000000, 11, ctypes.byref(slack)) == 0
+    assert slack.value > 0.05  # the farthest box corner found stays that far inside the ball
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for scene in ("fractal2", "gyroid"):
+        for eye, at in [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((1.3, 1.9, 0.2), (0.0, 0.8, 0.0)), ((0.2, 0.9, 0.1), (2.0, 1.5, 1.0)), ((9.0, 7.0, -8.0), (0.0, 0.5, 0.0)),
+                        ((0.0, 4.0, 0.01), (0.0, 0.0, 0.0))]:
+            f = oracle.default_frame(scene, 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.9)
+            ref, rst, _ = oracle.render(scene, f, stats=True)
+            hf = hostsim.frame_from_oracle(f)
+            img, st = hostsim.render(scene, hf)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (scene, eye)
+            assert np.array_equal(st, rst), (scene, eye)
+            hf.step_shortcuts = 1
+            img, st = hostsim.render(scene, hf)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (scene, eye, "shortcuts")
+            assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
