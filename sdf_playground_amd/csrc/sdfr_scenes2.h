@@ -546,13 +546,36 @@ struct SceneNeon
 		o.border = sd_box(mp, V3(1.05f, 1.75f, 0.04f));
 		return o;
 	}
+	// The rings are tubes of radius r2 about circles ON the sphere of radius r1 about (0, 2, 0): ring_sphere() is the distance to a point
+	// hp of that sphere minus r2, and |p - hp| >= | |p - c| - r1 | (triangle), so rings >= | |p - c| - r1 | - r2 outside and inside the
+	// sphere alike.  Where that (0.01 of slack for the rounding of hp) is not below floor, pane and frame, the rings -- an atan2, a sincos, two
+	// normalisations, a division -- cannot lower the minimum and are left out.  Checked numerically in tests/test_scene_bounds_cpu.py.
+	static SDF_HD float rings_lower_bound(const FrameU &U, vec3 p) { return abs1(length(p - V3(0.f, 2.f, 0.f)) - U.scene_var[0]) - U.scene_var[1] - 0.01f; }
+	// floor + rings (in the ball of radius r1 + r2 about (0, 2, 0)) + pane and frame (half size (1.05, 1.75, 0.05) about (0, 2, 2.75), whatever
+	// their yaw: in the ball of radius 2.05 about that point): a ray that does not descend and has both balls behind it or passes them
+	// at a distance, or is above both, has nothing left to hit
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir)
+	{
+		if (!(dir.y >= 0.f) || !(p.y > 1e-20f)) return false; // (as ray_leaves_floor_and_ball: sdfr_lib.h)
+		const float reach = abs1(U.scene_var[0]) + abs1(U.scene_var[1]) + 0.02f;
+		if (p.y > 2.f + max1(reach, 1.77f)) return true;
+		const vec3 v1 = p - V3(0.f, 2.f, 0.f), v2 = p - V3(0.f, 2.f, 2.75f);
+		const float b1 = dot(v1, dir), c1 = dot(v1, v1), b2 = dot(v2, dir), c2 = dot(v2, v2);
+		return c1 > reach * reach && (b1 >= 0.f || c1 - b1 * b1 > reach * reach) && c2 > 2.07f * 2.07f && (b2 >= 0.f || c2 - b2 * b2 > 2.07f * 2.07f);
+	}
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		const Objects o = eval_objects(U, p);
-		d = min1(d, o.rings);
-		d = min1(d, o.mirror);
-		return min1(d, o.border);
+		vec3 mp = p - V3(0.f, 2.f, 2.75f);
+		const vec2 r = rot2(V2(mp.x, mp.z), U.su[SU_MIRROR_S], U.su[SU_MIRROR_C]);
+		mp = V3(r.x, mp.y, r.y);
+		const float mirror = sd_box(mp, V3(1.f, 1.7f, 0.05f)), border = sd_box(mp, V3(1.05f, 1.75f, 0.04f));
+		// min() over the same four values as map(), the rings in their place when they are needed
+		if (!(rings_lower_bound(U, p) >= min1(min1(d, mirror), border)))
+			d = min1(d, ring_sphere(p - V3(0.f, 2.f, 0.f), U.scene_var[2], U.scene_var[0], U.scene_var[1]));
+		d = min1(d, mirror);
+		return min1(d, border);
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

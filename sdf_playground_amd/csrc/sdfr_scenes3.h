@@ -150,7 +150,7 @@ struct SceneSpiral
 	static constexpr bool shadow_hits_need_normal = false; // material() does not read sp.normal
 	static const char *variables() { return ""; }
 	// a spring hopping along a parabola: everything about the hop is frame-uniform
-	enum { SU_SHIFT_X = 0, SU_SPRING_S, SU_SPRING_C, SU_CENTER_Y, SU_LENGTH };
+	enum { SU_SHIFT_X = 0, SU_SPRING_S, SU_SPRING_C, SU_CENTER_Y, SU_LENGTH, SU_REACH };
 	static SDF_HD void prepare(FrameU &U)
 	{
 		const float speed = 1.5f, width = 4.f, height = 6.f, pen = 2.f;
@@ -169,6 +169,10 @@ struct SceneSpiral
 		U.su[SU_SPRING_C] = sc.y;
 		U.su[SU_CENTER_Y] = (y_top + y_bottom) * 0.5f + 0.1f;
 		U.su[SU_LENGTH] = y_top - y_bottom;
+		// the spring's bounding ball about its middle (spring_lower_bound below: within 0.102 of the tube's circle radially, and within
+		// pitch + 0.102 of its ends along the axis, nothing is nearer than 0.002)
+		const float len = y_top - y_bottom, half = len * 0.5f + len / 4.5f + 0.102f;
+		U.su[SU_REACH] = sqrt1(1.102f * 1.102f + half * half) + 0.02f;
 	}
 	struct RayInv { GroundInv ground; };
 	static SDF_HD RayInv ray_setup(const FrameU &U, vec3 dir, const RayFlags &)
@@ -204,13 +208,35 @@ struct SceneSpiral
 		const float len = U.su[SU_LENGTH];
 		return helix(q + V3(0.f, len * 0.5f, 0.f), 1.f, len, 0.1f, 0.f, 4.5f * SDFR_TAU) * 0.98f;
 	}
+	// A lower bound of spring() without the helix (an atan2, a rounding, three lengths).  In the spring's frame, rho the distance from its
+	// axis and y the height above its lower end: the tube's distance is length(rho - 1, axial) - 0.1 with |axial| >= dist(y, [0, h]) - pitch
+	// (the nearest turn is sought within half a pitch of the clamped height, the helix's own offset is another half), and the caps sit
+	// on that circle at y = 0 and y = h: everything is >= max(|rho - 1|, dist(y, [0, h]) - pitch) - 0.1, times the scene's 0.98.  0.01 of
+	// slack.  Checked numerically in tests/test_scene_bounds_cpu.py.
+	static SDF_HD float spring_lower_bound(const FrameU &U, vec3 p)
+	{
+		vec3 q = p;
+		q.y = q.y - U.su[SU_CENTER_Y];
+		const vec2 r = rot2(V2(q.x, q.y), U.su[SU_SPRING_S], U.su[SU_SPRING_C]);
+		const float len = U.su[SU_LENGTH];
+		const float y = r.y + len * 0.5f;
+		const float beyond = max1(max1(-y, y - len), 0.f) - len / 4.5f;
+		const float rho = length(V2(r.x, q.z));
+		return (max1(abs1(rho - 1.f), beyond) - 0.1f) * 0.98f - 0.01f;
+	}
+	// floor + the spring, inside the ball of radius SU_REACH about its middle (0, SU_CENTER_Y, 0)
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir)
+	{
+		return ray_leaves_floor_and_ball(p, dir, U.su[SU_CENTER_Y] + U.su[SU_REACH], V3(0.f, U.su[SU_CENTER_Y], 0.f), U.su[SU_REACH]);
+	}
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	// the floor scrolls under the spring: it is evaluated at x + shift
 	static SDF_HD vec3 scrolled(const FrameU &U, vec3 p) { return V3(p.x + U.su[SU_SHIFT_X], p.y, p.z); }
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
-		const float obj = spring(U, p);
 		float d = min1(3e38f, ground_dist(scrolled(U, p), fast, R.ground));
-		return min1(d, obj);
+		if (spring_lower_bound(U, p) >= d) return d;
+		return min1(d, spring(U, p));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

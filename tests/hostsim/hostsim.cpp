@@ -228,6 +228,74 @@ extern "C" long long hostsim_check_fractal2_gyroid_bounds(long long n, unsigned 
 	return bad;
 }
 
+// neon's rings (sdfr_scenes2.h): never below | |p - c| - r1 | - r2 - 0.01, whatever the sliders
+extern "C" long long hostsim_check_neon_rings_bound(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 3131ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	FrameU U;
+	frame_defaults(U);
+	for (long long i = 0; i < n; ++i)
+	{
+		if (i % 100 == 0)
+		{
+			U.scene_var[0] = 0.2f + rnd() * 1.8f;     // r1
+			U.scene_var[1] = 0.005f + rnd() * 0.095f; // r2
+			U.scene_var[2] = 0.01f + rnd() * 0.19f;   // spacing
+		}
+		const float span = (i % 3 == 0) ? 0.3f : ((i % 3 == 1) ? 3.f : 60.f);
+		vec3 v = V3(rnd() * 2.f - 1.f, rnd() * 2.f - 1.f, rnd() * 2.f - 1.f);
+		const float len = length(v);
+		if (len < 1e-3f) continue;
+		// around the sphere the rings lie on, room-scale, far away
+		const vec3 p = V3(0.f, 2.f, 0.f) + v * ((i % 3 == 0 ? U.scene_var[0] : 0.f) / len) + V3(rnd() * 2.f - 1.f, rnd() * 2.f - 1.f, rnd() * 2.f - 1.f) * span;
+		const float g = SceneNeon::ring_sphere(p - V3(0.f, 2.f, 0.f), U.scene_var[2], U.scene_var[0], U.scene_var[1]);
+		const float lb = SceneNeon::rings_lower_bound(U, p);
+		if (!(lb <= g)) ++bad;
+		if ((double)g - (double)lb < slack) slack = (double)g - (double)lb;
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
+// the spiral's spring (sdfr_scenes3.h): never below spring_lower_bound(), at any time of its hop; outside its bounding ball
+// (SU_REACH about its middle) it is farther than any dist_eps the library accepts
+extern "C" long long hostsim_check_spiral_bounds(long long n, unsigned seed, double *min_slack)
+{
+	unsigned long long state = seed * 2654435761ull + 5151ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0;
+	double slack = 1e30;
+	FrameU U;
+	frame_defaults(U);
+	for (long long i = 0; i < n; ++i)
+	{
+		if (i % 500 == 0)
+		{
+			U.stime = rnd() * 40.f;
+			SceneSpiral::prepare(U);
+		}
+		const float span = (i % 3 == 0) ? 1.5f : ((i % 3 == 1) ? 5.f : 80.f);
+		const vec3 p = V3(0.f, U.su[SceneSpiral::SU_CENTER_Y], 0.f) + V3(rnd() * 2.f - 1.f, rnd() * 2.f - 1.f, rnd() * 2.f - 1.f) * span;
+		const float g = SceneSpiral::spring(U, p);
+		const float lb = SceneSpiral::spring_lower_bound(U, p);
+		if (!(lb <= g)) ++bad;
+		if ((double)g - (double)lb < slack) slack = (double)g - (double)lb;
+		const vec3 v = p - V3(0.f, U.su[SceneSpiral::SU_CENTER_Y], 0.f);
+		if (length(v) >= U.su[SceneSpiral::SU_REACH] && !(g >= 0.002f)) ++bad;
+	}
+	if (min_slack) *min_slack = slack;
+	return bad;
+}
+
 // the distortion scene's lower bound of the displaced wall (sdfr_scenes2.h)
 extern "C" long long hostsim_check_distortion_bounds(long long n, unsigned seed)
 {

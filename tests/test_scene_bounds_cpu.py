@@ -251,3 +251,57 @@ def test_fractal2_ball_and_gyroid_cull(oracle):
             img, st = hostsim.render(scene, hf)
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (scene, eye, "shortcuts")
             assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
+
+
+def test_neon_rings_bound_and_escape_rule(oracle):
+    """neon's rings lie on a sphere: their distance is never below | |p - c| - r1 | - r2 - 0.01 for any slider setting (the cull of
+    their evaluation, the ball of the escape rule); frames with the sliders moved keep their bits with and without step shortcuts"""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_neon_rings_bound.restype = ctypes.c_longlong
+    L.hostsim_check_neon_rings_bound.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_neon_rings_bound(4000000, 13, ctypes.byref(slack)) == 0
+    assert slack.value > 0.005  # the 0.01 of slack is not eaten by rounding
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for k, (eye, at) in enumerate([((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((0.1, 2.05, 0.2), (0.0, 2.0, 2.75)), ((3.0, 0.5, 5.0), (0.0, 2.0, 1.0)), ((0.0, 9.0, 0.5), (0.0, 2.0, 1.0)),
+                                   ((-2.0, 3.0, 6.0), (0.0, 2.0, 0.0))]):
+        f = oracle.default_frame("neon", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.9)
+        if k % 2:
+            f.scene_var[0], f.scene_var[1], f.scene_var[2] = 1.9, 0.09, 0.03
+        ref, rst, _ = oracle.render("neon", f, stats=True)
+        hf = hostsim.frame_from_oracle(f)
+        img, st = hostsim.render("neon", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), eye
+        assert np.array_equal(st, rst), eye
+        hf.step_shortcuts = 1
+        img, st = hostsim.render("neon", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, "shortcuts")
+        assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
+
+
+def test_spiral_spring_bound_and_ball(oracle):
+    """the hopping spring is never nearer than spring_lower_bound() says (the cull of its helix) and lies inside its bounding ball (the
+    escape rule), at any time of the hop; frames keep their bits with and without step shortcuts"""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_spiral_bounds.restype = ctypes.c_longlong
+    L.hostsim_check_spiral_bounds.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    slack = ctypes.c_double(0)
+    assert L.hostsim_check_spiral_bounds(4000000, 19, ctypes.byref(slack)) == 0
+    assert slack.value > 0.005
+    fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
+    for k, (eye, at) in enumerate([((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((-2.93, 4.23, -4.22), (1.0, 2.5, 0.0)), ((0.3, 1.0, 0.2), (0.0, 5.0, 0.0)), ((6.0, 0.3, 6.0), (0.0, 2.0, 0.0)),
+                                   ((0.0, 12.0, 0.1), (0.0, 0.0, 0.0))]):
+        f = oracle.default_frame("spiral", 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.55 * k + 0.1)
+        ref, rst, _ = oracle.render("spiral", f, stats=True)
+        hf = hostsim.frame_from_oracle(f)
+        img, st = hostsim.render("spiral", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), eye
+        assert np.array_equal(st, rst), eye
+        hf.step_shortcuts = 1
+        img, st = hostsim.render("spiral", hf)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, "shortcuts")
+        assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
