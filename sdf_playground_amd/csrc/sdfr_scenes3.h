@@ -117,6 +117,10 @@ struct SceneShell
 		c = op_shell(c, -0.05f, 0.05f);
 		return max1(c, -sd_plane(p, V3(-1.f, 0.f, 0.f)));
 	}
+	// op_shell(d, inner, outer) = |d - middle| - half >= d - outer, so shells() >= cube - 0.35 >= |p - (0, 1, 0)| - 0.866 - 0.35: the shells
+	// lie in the ball of radius 1.2161 about the cube's centre (1.24: slack), below y = 2.24; a ray that leaves it and the floor is a miss
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 2.25f, V3(0.f, 1.f, 0.f), 1.24f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, shells(p));

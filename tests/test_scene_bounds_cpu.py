@@ -227,8 +227,9 @@ def test_gems_bound_holds_and_culling_is_invisible(oracle):
 
 
 def test_fractal2_ball_and_gyroid_cull(oracle):
-    """fractal2's boxes lie in the ball of radius 1.21 about the fold's centre (its escape rule and the cull of its fold), and the
-    gyroid's shape() is its cube's distance from 0.22 off the cube, bit for bit; frames from outside, inside and far away keep their bits"""
+    """fractal2's boxes lie in the ball of radius 1.21 about the fold's centre (its escape rule and the cull of its fold), the shell
+    scene's shells in the ball of radius 1.2161 about their cube's, and the gyroid's shape() is its cube's distance from 0.22 off the
+    cube, bit for bit; frames from outside, inside and far away keep their bits"""
     import hostsim
 
     L = hostsim.lib()
@@ -238,7 +239,7 @@ def test_fractal2_ball_and_gyroid_cull(oracle):
     assert L.hostsim_check_fractal2_gyroid_bounds(4000000, 11, ctypes.byref(slack)) == 0
     assert slack.value > 0.05  # the farthest box corner found stays that far inside the ball
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
-    for scene in ("fractal2", "gyroid"):
+    for scene in ("fractal2", "gyroid", "shell"):
         for eye, at in [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((1.3, 1.9, 0.2), (0.0, 0.8, 0.0)), ((0.2, 0.9, 0.1), (2.0, 1.5, 1.0)), ((9.0, 7.0, -8.0), (0.0, 0.5, 0.0)),
                         ((0.0, 4.0, 0.01), (0.0, 0.0, 0.0))]:
             f = oracle.default_frame(scene, 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.9)
