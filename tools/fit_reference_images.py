@@ -56,6 +56,9 @@ TARGETS = {
     # taken with an older version of the scene file, whose lights' phases step the other way (oracle/scenes.h: SceneLightShadowsT)
     "multi-lights": ("multi-lights.png", "light_shadows_backwards", None, {}),
     "multi-lights-todays-file": ("multi-lights.png", "light_shadows", None, {}),
+    # the scene of BASELINE configuration 5 at its default sliders: two lattices of reflecting blobs, a refracting lens, an emissive ball, a
+    # half-mirror in a wooden frame turning with the time
+    "lense1": ("lense1.png", "lense", None, {}),
     # a spring that hops along a parabola while the floor scrolls under it (period 8 / 3 s of stime); the sky: see ROWS_FROM
     "spiral": ("spiral.png", "spiral", None, {}),
 }
