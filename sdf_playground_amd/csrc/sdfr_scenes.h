@@ -771,6 +771,10 @@ struct SceneLightShadows
 		r.is_shadow = f.is_shadow;
 		return r;
 	}
+	// The rounded cubes end at y = 1.5 (centre 1, half size 0.4, rounded by 0.1), the light bulbs -- spheres of radius 0.2 whose centres bob
+	// between y = 1 and 3, and which a shadow ray does not see at all -- at 3.2: a ray that does not descend (the floor is behind it) is
+	// gone above that (0.02 of slack).
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &R, vec3 p, vec3 dir) { return dir.y >= 0.f && p.y > (R.is_shadow ? 1.52f : 3.22f); }
 	static SDF_HD float cubes(vec3 p)
 	{
 		vec2 rep = op_rep_lim(V2(p.x, p.z), V2(2.f, 2.f), V2(3.f, 3.f));

@@ -396,6 +396,9 @@ struct SceneTiling
 		r.ground = ground_setup(dir);
 		return r;
 	}
+	// panes (centre height 4, half height 2) and cable (a cylinder of half height 2 about y = 4) end at y = 6: a ray above that which does
+	// not descend has them and the floor behind it
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return dir.y >= 0.f && p.y > 6.02f; }
 	static SDF_HD float pane(vec3 p, float x) { return sd_box(p - V3(x, 4.f, 0.f), V3(1.f, 2.f, 0.05f)); }
 	static SDF_HD float cable(vec3 p) { return sd_capped_cylinder(p - V3(4.f, 4.f, 4.f), 2.f, 0.1f); }
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
