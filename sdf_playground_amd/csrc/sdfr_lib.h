@@ -113,7 +113,9 @@ SDF_HD float sd_plane(vec3 p, vec3 n) { return dot(p, n); }
 // For Scene::ray_escapes of a scene that is a floor at y = 0 plus objects inside the ball (c, radius) and below `top`:
 // a ray that does not descend has the floor behind it, and leaves the objects behind for good once it is above `top`,
 // or if its line passes the ball at more than the radius, or if the ball lies behind it.  `radius` and `top` carry the
-// caller's slack (the direction is a unit vector to 1e-7 only).
+// caller's slack.  The direction is NOT taken to be a unit vector: a shadow ray towards a directional light has length
+// |L| / (|L| + dist_eps) (pshader_sdf.hlsl: the reference's own normalisation), 0.9996 at the largest dist_eps, and over a lever
+// of ten units that moves the line's distance from the centre by more than the slack (found by the randomised hunt in round 4).
 // "Behind it" needs the ray to be ABOVE the floor: the fast plane of a ray that does not descend is p.y / 1e-20
 // (ground_dist), which for p.y <= 0 -- a camera under or on the floor, a child ray pushed below it -- is <= 0: the
 // reference books a HIT of the floor at that very sample.  From p.y > 1e-20 on the floor's distance is >= 1 here and
@@ -123,8 +125,15 @@ SDF_HD bool ray_leaves_floor_and_ball(vec3 p, vec3 dir, float top, vec3 c, float
 	if (!(dir.y >= 0.f) || !(p.y > 1e-20f)) return false;
 	if (p.y > top) return true;
 	const vec3 v = p - c;
-	const float b = dot(v, dir), vv = dot(v, v);
-	return vv > radius * radius && (b >= 0.f || vv - b * b > radius * radius);
+	const float b = dot(v, dir), vv = dot(v, v), dd = dot(dir, dir);
+	return vv > radius * radius && (b >= 0.f || vv * dd - b * b > radius * radius * dd);
+}
+// the same test for one ball alone: the ray has it behind or passes it at a distance
+SDF_HD bool ray_passes_ball(vec3 p, vec3 dir, vec3 c, float radius)
+{
+	const vec3 v = p - c;
+	const float b = dot(v, dir), vv = dot(v, v), dd = dot(dir, dir);
+	return vv > radius * radius && (b >= 0.f || vv * dd - b * b > radius * radius * dd);
 }
 
 // distance along the ray when `fast` (sdf_primitives.hlsl:59-70)

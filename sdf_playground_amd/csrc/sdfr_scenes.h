@@ -508,23 +508,37 @@ struct SceneLense
 	// Between the two blob fields (blob >= |h| - 1.11: nothing of them where |y| < 3.88) lie only the lens (in the ball of radius 2 about
 	// the origin), the light ball (radius 2) and the pane with its frame (in the ball of radius 2.38 about (0, 0, -5)).  What a ray has
 	// left to go -- a shadow ray ends at its light, and the extension lights hang 3 high -- meets nothing once it is in that slab for
-	// good (it ends there, and has crossed |y| = 3.86 if it started outside) and has each ball behind it or passes it at a distance:
-	// the distance along the ray from which that holds.  0.01 - 0.02 of slack for rounding (dir is a unit vector to 1e-7); NaN or an
+	// good (it ends there, or leaves it through a gap of the upper field: below; and has crossed |y| = 3.86 if it started outside) and
+	// has each ball behind it or passes it at a distance:
+	// the distance along the ray from which that holds.  0.01 - 0.02 of slack for rounding; NaN or an
 	// end outside the slab: never.
 	static SDF_HD float ball_left_behind(vec3 start, vec3 dir, vec3 c, float radius)
 	{
 		const vec3 v = start - c;
-		const float b = dot(v, dir), cc = dot(v, v) - radius * radius;
-		const float disc = b * b - cc;
+		const float b = dot(v, dir), cc = dot(v, v) - radius * radius, dd = dot(dir, dir); // (dir need not be a unit vector: sdfr_lib.h)
+		const float disc = b * b - cc * dd;
 		if (disc < 0.f) return 0.f; // the line passes at a distance
-		return (sqrt1(disc) - b) + 0.01f; // the far intersection (NaN stays NaN)
+		return (sqrt1(disc) - b) / dd + 0.01f; // the far intersection (NaN stays NaN)
 	}
 	static SDF_HD float escapes_from(const FrameU &U, vec3 start, vec3 dir, float range)
 	{
 		const float y_end = start.y + dir.y * range;
-		if (!(abs1(y_end) < 3.86f)) return 3e38f;
 		float t = 0.f;
-		if (!(abs1(start.y) < 3.86f)) t = ((start.y > 0.f ? 3.86f : -3.86f) - start.y) / dir.y; // y(t) = +-3.86: from there to the end inside the slab
+		if (!(abs1(y_end) < 3.86f))
+		{
+			// ... or it leaves through the upper field, whose blobs (within 1.11 of the centres of 10 x 10 cells) are mostly gaps, and there is
+			// nothing above: while y runs from 3.86 to 6.14 the ray covers an interval of x and one of z; if either stays clear of every
+			// centre's band, no blob is met.  (A ray that starts on a blob of that field starts inside both bands.)  Towards the sun: 7 in 10.
+			if (!(dir.y > 1e-3f) || !(y_end > 6.2f)) return 3e38f;
+			const float inv = 1.f / dir.y;
+			const float ta = (max1(start.y, 3.86f) - start.y) * inv, tb = max1((6.14f - start.y) * inv, 0.f);
+			const float xa = start.x + dir.x * ta, xb = start.x + dir.x * tb, za = start.z + dir.z * ta, zb = start.z + dir.z * tb;
+			const float xl = (min1(xa, xb) - 1.13f) * 0.1f, xh = (max1(xa, xb) + 1.13f) * 0.1f, zl = (min1(za, zb) - 1.13f) * 0.1f, zh = (max1(za, zb) + 1.13f) * 0.1f;
+			const bool clear_x = floor1(xl) == floor1(xh) && xl > floor1(xl), clear_z = floor1(zl) == floor1(zh) && zl > floor1(zl);
+			if (!((clear_x || clear_z) && abs1(start.x) < 1e4f && abs1(start.z) < 1e4f)) return 3e38f;
+			if (start.y < -3.86f) t = (-3.86f - start.y) * inv; // out of the lower field first
+		}
+		else if (!(abs1(start.y) < 3.86f)) t = ((start.y > 0.f ? 3.86f : -3.86f) - start.y) / dir.y; // y(t) = +-3.86: from there to the end inside the slab
 		const vec3 ball = V3(U.scene_var[SV_XPOS], U.scene_var[SV_YPOS], U.scene_var[SV_ZPOS]);
 		const float t0 = ball_left_behind(start, dir, V3(0.f, 0.f, 0.f), 2.02f), t1 = ball_left_behind(start, dir, ball, 2.02f), t2 = ball_left_behind(start, dir, V3(0.f, 0.f, -5.f), 2.40f);
 		t = max1(max1(t, t0), max1(t1, t2));

@@ -74,8 +74,7 @@ struct SceneGyroid
 	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir)
 	{
 		if ((abs1(p.x) > 1.01f && p.x * dir.x >= 0.f) || (abs1(p.y) > 1.01f && p.y * dir.y >= 0.f) || (abs1(p.z) > 1.01f && p.z * dir.z >= 0.f)) return true;
-		const float b = dot(p, dir), vv = dot(p, p);
-		return vv > 1.75f * 1.75f && (b >= 0.f || vv - b * b > 1.75f * 1.75f);
+		return ray_passes_ball(p, dir, V3s(0.f), 1.75f);
 	}
 	// a gyroid shell clipped to the unit cube; no floor in this scene.  The shell's term is |sin x cos z + sin y cos x + sin z cos y| / 14
 	// - 0.01 <= 3 / 14 - 0.01 = 0.2043: from 0.22 off the cube max() returns the cube's distance, and the three sincos are left out.
@@ -559,9 +558,7 @@ struct SceneNeon
 		if (!(dir.y >= 0.f) || !(p.y > 1e-20f)) return false; // (as ray_leaves_floor_and_ball: sdfr_lib.h)
 		const float reach = abs1(U.scene_var[0]) + abs1(U.scene_var[1]) + 0.02f;
 		if (p.y > 2.f + max1(reach, 1.77f)) return true;
-		const vec3 v1 = p - V3(0.f, 2.f, 0.f), v2 = p - V3(0.f, 2.f, 2.75f);
-		const float b1 = dot(v1, dir), c1 = dot(v1, v1), b2 = dot(v2, dir), c2 = dot(v2, v2);
-		return c1 > reach * reach && (b1 >= 0.f || c1 - b1 * b1 > reach * reach) && c2 > 2.07f * 2.07f && (b2 >= 0.f || c2 - b2 * b2 > 2.07f * 2.07f);
+		return ray_passes_ball(p, dir, V3(0.f, 2.f, 0.f), reach) && ray_passes_ball(p, dir, V3(0.f, 2.f, 2.75f), 2.07f);
 	}
 	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)

@@ -282,8 +282,7 @@ struct SceneTerrain
 		if (R.rising && p.y > 0.37f) return true;
 		// ... or beyond any other face of the box and not coming back (shape() >= the box's distance >= |p_i| - 5 on every axis)
 		if ((abs1(p.x) > 5.01f && p.x * dir.x >= 0.f) || (abs1(p.z) > 5.01f && p.z * dir.z >= 0.f) || (p.y < -5.01f && dir.y <= 0.f)) return true;
-		const float b = dot(p, dir), vv = dot(p, p);
-		return vv > 8.7f * 8.7f && (b >= 0.f || vv - b * b > 8.7f * 8.7f);
+		return ray_passes_ball(p, dir, V3s(0.f), 8.7f);
 	}
 	static SDF_HD float lattice_noise(vec3 p) { return frac1(sin1(dot(p, V3(12.9898f, 78.233f, 34.531247f))) * 43758.5453f); }
 	static SDF_HD float corner_sphere(vec3 cell, vec3 p, vec3 off)

@@ -572,3 +572,52 @@ extern "C" long long hostsim_trace_tiles(const char *scene, FrameU *frame, int s
 	for (auto &th : pool) th.join();
 	return (long long)tiles.size();
 }
+
+// SceneLense::escapes_from against a dense walk along the ray: from the distance it returns on, nothing of the scene is nearer
+// than 0.002 (twice the largest dist_eps the library accepts) up to the range
+extern "C" long long hostsim_check_lense_escape_rule(long long n, unsigned seed, long long *fired, float *witness)
+{
+	unsigned long long state = seed * 2654435761ull + 8118ull;
+	auto rnd = [&]() {
+		state = state * 6364136223846793005ull + 1442695040888963407ull;
+		return (float)((state >> 40) & 0xffffff) / 16777216.f;
+	};
+	long long bad = 0, clear = 0;
+	FrameU U;
+	frame_defaults(U);
+	const int si = scene_index("lense");
+	for (long long i = 0; i < n; ++i)
+	{
+		if (i % 200 == 0)
+		{
+			U.stime = rnd() * 60.f;
+			U.scene_var[0] = (rnd() * 2.f - 1.f) * 4.f;
+			U.scene_var[1] = (rnd() * 2.f - 1.f) * 4.f;
+			U.scene_var[2] = rnd() * 25.f;
+			frame_derive(U, si);
+		}
+		const vec3 s = V3((rnd() * 2.f - 1.f) * 40.f, (i % 3 == 0) ? -3.9f - rnd() * 1.2f : (rnd() * 2.f - 1.f) * 6.5f, (rnd() * 2.f - 1.f) * 40.f);
+		vec3 d;
+		float range;
+		// towards a directional light the direction is |L| / (|L| + dist_eps) long, not 1 (sdfr_lib.h, ray_leaves_floor_and_ball)
+		if (i % 2 == 0) { d = normalize(V3(1.f, 1.f, -2.f) + V3(rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f) * ((i % 4 == 0) ? 0.f : 3.f)) * (1.f - rnd() * 6e-4f); range = 100.f; }
+		else { const vec3 to = V3((rnd() * 2.f - 1.f) * 5.f, 3.f, (rnd() * 2.f - 1.f) * 5.f); d = normalize(to - s); range = length(to - s) - 0.25f; }
+		const float t0 = SceneLense::escapes_from(U, s, d, range);
+		if (!(t0 < 1e30f)) continue;
+		++clear;
+		SceneLense::RayInv R = SceneLense::ray_setup(U, d, RayFlags());
+		const float end = min1(range, 60.f);
+		for (float t = t0; t <= end; t += 0.01f + rnd() * 0.02f)
+		{
+			const vec3 p = mad(d, t, s);
+			if (!(SceneLense::dist(U, R, p, d, true) >= 0.002f))
+			{
+				if (bad == 0 && witness) { witness[0] = s.x; witness[1] = s.y; witness[2] = s.z; witness[3] = d.x; witness[4] = d.y; witness[5] = d.z; witness[6] = t; witness[7] = t0; witness[8] = range; }
+				++bad;
+				break;
+			}
+		}
+	}
+	if (fired) *fired = clear;
+	return bad;
+}

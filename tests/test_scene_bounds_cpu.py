@@ -306,3 +306,19 @@ def test_spiral_spring_bound_and_ball(oracle):
         img, st = hostsim.render("spiral", hf)
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (eye, "shortcuts")
         assert np.array_equal(st[..., 0], rst[..., 0]) and np.array_equal(st[..., 2], rst[..., 2]) and (st[..., 1] <= rst[..., 1]).all()
+
+
+def test_lense_escape_distance_against_a_walk_along_the_ray(oracle):
+    """SceneLense::escapes_from says from which distance on a ray meets nothing: a dense walk along 150 000 rays -- towards the sun
+    (whose direction vector is shorter than 1 by up to dist_eps / |L|: the lever that broke a first version), towards lights
+    between the fields, from inside and outside the slabs, the light ball anywhere -- finds the scene farther than 0.002 everywhere
+    beyond that distance."""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_lense_escape_rule.restype = ctypes.c_longlong
+    L.hostsim_check_lense_escape_rule.argtypes = [ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_float)]
+    fired = ctypes.c_longlong(0)
+    witness = (ctypes.c_float * 9)()
+    assert L.hostsim_check_lense_escape_rule(150000, 29, ctypes.byref(fired), witness) == 0, list(witness)
+    assert fired.value > 30000
