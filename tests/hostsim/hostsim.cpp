@@ -621,3 +621,63 @@ extern "C" long long hostsim_check_lense_escape_rule(long long n, unsigned seed,
 	if (fired) *fired = clear;
 	return bad;
 }
+
+// Every built-in scene's ray_escapes() against a dense walk: wherever the rule calls a ray gone, the scene is farther than 0.002
+// (twice the largest dist_eps the library accepts) along the rest of it.  Directions are up to 6e-4 shorter than unit vectors (a
+// shadow ray towards a directional light), starts up to 45 away (the lever that turns that into a distance), the scene's variables
+// as the caller set them in *frame.  Returns the number of violations (-1: the scene has no such rule); *fired: how often the rule spoke.
+template <class Scene>
+static long long check_escape_rule(const FrameU &U, long long n, unsigned seed, long long *fired, float *witness)
+{
+	if constexpr (!RayEscapes<Scene>::available) return -1;
+	else
+	{
+		unsigned long long state = seed * 2654435761ull + 6262ull;
+		auto rnd = [&]() {
+			state = state * 6364136223846793005ull + 1442695040888963407ull;
+			return (float)((state >> 40) & 0xffffff) / 16777216.f;
+		};
+		long long bad = 0, spoke = 0;
+		for (long long i = 0; i < n; ++i)
+		{
+			const float span = (i % 3 == 0) ? 45.f : ((i % 3 == 1) ? 8.f : 2.5f);
+			const vec3 s = V3((rnd() * 2.f - 1.f) * span, (i % 5 == 0) ? rnd() * 0.01f : -1.f + rnd() * 9.f, (rnd() * 2.f - 1.f) * span);
+			vec3 d = V3(rnd() * 2.f - 1.f, (i % 4 == 0) ? rnd() * 0.2f : rnd() * 2.f - 0.7f, rnd() * 2.f - 1.f);
+			if (i % 7 == 0) d = V3(1.f, 1.f, -2.f); // the sun of most scenes
+			if (!(length(d) > 1e-3f)) continue;
+			d = normalize(d) * (1.f - ((i & 1) ? rnd() * 6e-4f : 0.f));
+			RayFlags f;
+			f.has_transparent = false;
+			f.is_shadow = rnd() < 0.5f;
+			f.last_transparent_pos = V3s(0.f);
+			const typename Scene::RayInv R = Scene::ray_setup(U, d, f);
+			if (!Scene::ray_escapes(U, R, s, d)) continue;
+			++spoke;
+			for (float t = 0.f; t <= 70.f; t += (t < 8.f ? 0.004f : 0.02f) + rnd() * 0.01f)
+			{
+				const vec3 p = mad(d, t, s);
+				if (!(Scene::dist(U, R, p, d, true) >= 0.002f))
+				{
+					if (bad == 0 && witness) { witness[0] = s.x; witness[1] = s.y; witness[2] = s.z; witness[3] = d.x; witness[4] = d.y; witness[5] = d.z; witness[6] = t; }
+					++bad;
+					break;
+				}
+			}
+		}
+		if (fired) *fired = spoke;
+		return bad;
+	}
+}
+extern "C" long long hostsim_check_escape_rule(const char *scene, FrameU *frame, long long n, unsigned seed, long long *fired, float *witness)
+{
+	const int si = scene_index(scene);
+	if (si < 0) return -2;
+	frame_derive(*frame, si);
+	switch (si)
+	{
+#define SDFR_CHK(I, S) case I: return check_escape_rule<S>(*frame, n, seed, fired, witness);
+		SDFR_FOR_EACH_SCENE(SDFR_CHK)
+#undef SDFR_CHK
+	}
+	return -2;
+}

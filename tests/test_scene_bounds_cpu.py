@@ -322,3 +322,40 @@ def test_lense_escape_distance_against_a_walk_along_the_ray(oracle):
     witness = (ctypes.c_float * 9)()
     assert L.hostsim_check_lense_escape_rule(150000, 29, ctypes.byref(fired), witness) == 0, list(witness)
     assert fired.value > 30000
+
+
+def test_every_escape_rule_against_a_walk_along_the_ray(oracle):
+    """Every built-in scene's ray_escapes(): wherever it calls a ray gone -- from starts up to 45 away, along directions up to 6e-4
+    shorter than unit vectors (a shadow ray towards a directional light), at random times and slider settings -- a dense walk along
+    the rest of the ray finds the scene farther than 0.002, twice the largest dist_eps the library accepts."""
+    import hostsim
+
+    L = hostsim.lib()
+    L.hostsim_check_escape_rule.restype = ctypes.c_longlong
+    L.hostsim_check_escape_rule.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_uint, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_float)]
+    L.hostsim_scene_count.restype = ctypes.c_int
+    L.hostsim_scene_name.restype = ctypes.c_char_p
+    L.hostsim_scene_name.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(20261107)
+    with_rule = []
+    for k in range(L.hostsim_scene_count()):
+        scene = L.hostsim_scene_name(k).decode()
+        table = oracle.var_table(scene)
+        total = 0
+        for rep in range(4):
+            f = oracle.default_frame(scene, 64, 48, stime=float(rng.uniform(0, 40)))
+            for name, mn, mx, start, _st, _v, slot in table:
+                if slot >= 0 and rep:
+                    f.scene_var[slot] = float(np.float32(rng.uniform(mn, mx)))
+            hf = hostsim.frame_from_oracle(f)
+            fired = ctypes.c_longlong(0)
+            witness = (ctypes.c_float * 7)()
+            bad = L.hostsim_check_escape_rule(scene.encode(), ctypes.byref(hf), 2000 if scene in ("tree", "terrain", "distortion") else 6000, 100 + rep, ctypes.byref(fired), witness)
+            if bad == -1:
+                break
+            assert bad == 0, (scene, list(witness), [f.scene_var[i] for i in range(8)], f.stime)
+            total += fired.value
+        else:
+            with_rule.append(scene)
+            assert total > 300, (scene, total)
+    assert len(with_rule) >= 20, with_rule
