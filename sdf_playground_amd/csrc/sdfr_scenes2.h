@@ -167,6 +167,9 @@ struct SceneBasicClouds
 		r.skip_cloud = f.has_transparent && slab(f.last_transparent_pos) < U.dist_eps;
 		return r;
 	}
+	// floor + the cloud's slab, half size (2, 0.5, 2) about (0, 5, 0): below y = 5.5, inside the ball of radius sqrt(8.25) = 2.873 about its centre
+	static SDF_HD bool ray_escapes(const FrameU &U, const RayInv &, vec3 p, vec3 dir) { return ray_leaves_floor_and_ball(p, dir, 5.52f, V3(0.f, 5.f, 0.f), 2.9f); }
+	static constexpr bool inline_escaped_shadows = true; // shadow rays that escape where they start are not queued (sdfr_pixel.h)
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));

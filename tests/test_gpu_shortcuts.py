@@ -68,7 +68,7 @@ def test_cube_sea_shortcuts_change_no_pixel(renderer, oracle, view):
                                           ("fractal", dict(iter_count=512)), ("gems", dict(max_cost_default=9, extension_lights=7)),
                                           ("tree", None), ("terrain", None), ("distortion", None), ("fast_sphere", None), ("cube", None), ("sierpinski", None),
                                           ("basic_transparency", None), ("coordinate_material", None), ("table", None),
-                                          ("light_shadows", None), ("tiling", None), ("gyroid", None), ("fractal2", None), ("neon", None), ("spiral", None), ("shell", None),
+                                          ("light_shadows", None), ("tiling", None), ("gyroid", None), ("fractal2", None), ("neon", None), ("spiral", None), ("shell", None), ("basic_clouds", None),
                                           ("cube_sea", dict(max_cost_default=6))])
 def test_scenes_with_an_escape_rule(renderer, oracle, scene, limits):
     """every scene that declares ray_escapes(), at the parity tests' camera and from six more (looking up from the

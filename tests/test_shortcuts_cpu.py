@@ -69,7 +69,7 @@ def test_every_scene_keeps_pixels_rays_and_hits_with_shortcuts(oracle):
             saved[scene] = saved.get(scene, 0) + int(st0[..., 1].sum()) - int(st1[..., 1].sum())
     # the rules do fire on these views (a test that compares two identical code paths proves nothing)
     for scene in ("fast_sphere", "cube_sea", "labyrinth", "fractal", "gems", "cube", "sierpinski", "table", "light_shadows", "tiling", "terrain", "gyroid", "fractal2", "neon",
-                  "spiral", "shell"):
+                  "spiral", "shell", "basic_clouds"):
         assert saved[scene] > 0, scene
 
 
