@@ -689,7 +689,7 @@ SDF_HD vec3 shade_hit(const FrameU &U, const DebugFlags &F, const RayRec &ray, c
 					}
 				}
 			}
-			else
+			else // the reference's one loop: every light's ambient share and its shadow ray (body not re-indented: the headline kernel's code)
 			for (int i = 0; i < U.light_count; ++i)
 			{
 				Light L;
