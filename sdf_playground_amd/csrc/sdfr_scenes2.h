@@ -479,7 +479,11 @@ struct SceneSierpinski
 	static SDF_HD float dist(const FrameU &U, const RayInv &R, vec3 p, vec3, bool fast)
 	{
 		float d = min1(3e38f, ground_dist(p, fast, R.ground));
-		return min1(d, tetra(p - V3(0.f, 1.f, 0.f)));
+		// tetra(p) >= |p| - 1.001 (above): where that is not below the floor's distance the ten folds -- forty square roots -- are left out
+		const vec3 v = p - V3(0.f, 1.f, 0.f);
+		const float k = max1(d, 0.f) + 1.02f;
+		if (dot(v, v) >= k * k) return d;
+		return min1(d, tetra(v));
 	}
 	static SDF_HD void material(const FrameU &U, const SurfacePoint &sp, Material &m)
 	{

@@ -223,6 +223,8 @@ extern "C" long long hostsim_check_fractal2_gyroid_bounds(long long n, unsigned 
 		const float shell = abs1(dot(V3(sx.x, sy.x, sz.x), V3(sz.y, sx.y, sy.y)) / 14.f) - 0.01f;
 		if (f32_bits(SceneGyroid::shape(g)) != f32_bits(max1(shell, box))) ++bad;
 		if (!(shell <= 0.2045f)) ++bad;
+		// the gasket's ball: tetra() >= |p| - 1.001 (SceneSierpinski::dist leaves the folds out behind it)
+		if (!(SceneSierpinski::tetra(v) >= (r - 1.001f) - 1e-4f)) ++bad;
 		// the shell scene's ball: shells() >= |p - (0, 1, 0)| - 1.2161
 		if (!(SceneShell::shells(V3(0.f, 1.f, 0.f) + v) >= (r - 1.2161f) - 1e-5f)) ++bad;
 	}

@@ -239,7 +239,7 @@ def test_fractal2_ball_and_gyroid_cull(oracle):
     assert L.hostsim_check_fractal2_gyroid_bounds(4000000, 11, ctypes.byref(slack)) == 0
     assert slack.value > 0.05  # the farthest box corner found stays that far inside the ball
     fovy = np.float32(60.0) * np.float32(3.14159265358979) / np.float32(180.0)
-    for scene in ("fractal2", "gyroid", "shell"):
+    for scene in ("fractal2", "gyroid", "shell", "sierpinski"):
         for eye, at in [((0.0, 2.0, -3.0), (0.0, 1.0, 0.0)), ((1.3, 1.9, 0.2), (0.0, 0.8, 0.0)), ((0.2, 0.9, 0.1), (2.0, 1.5, 1.0)), ((9.0, 7.0, -8.0), (0.0, 0.5, 0.0)),
                         ((0.0, 4.0, 0.01), (0.0, 0.0, 0.0))]:
             f = oracle.default_frame(scene, 96, 64, basis=oracle.camera_lookat(eye, at, fovy, np.float32(1.5)), stime=0.9)
