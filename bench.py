@@ -295,6 +295,20 @@ def parse_args(argv=None):
 
 
 def _free_port():
+    """A port for the launcher's rendezvous: one that binds now, from below the ephemeral range -- a port handed out by bind(0) can be taken
+    as the source port of somebody's outgoing connection before torch.distributed.run listens on it (seen once on a GPU box: EADDRINUSE)."""
+    import random
+
+    for _ in range(64):
+        p = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+            return p
+        except OSError:
+            continue
+        finally:
+            s.close()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
@@ -306,11 +320,17 @@ def spawn_ranks(a, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes with
     torch.distributed.run and relay rank 0's JSON line and the exit code.  Runs before this process
     has made any GPU call, and starts children -- it never replaces itself."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        sys.stderr.write(p.stderr)
+        # the launcher could not listen on its port: no rank was started, nothing ran -- take another port (not a retry of a run that failed)
+        if p.returncode != 0 and "EADDRINUSE" in p.stderr and not p.stdout.strip():
+            continue
+        break
     line = None
     for l in p.stdout.splitlines():
         try:
