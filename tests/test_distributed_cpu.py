@@ -15,11 +15,21 @@ W, H = 40, 27  # ragged last strip
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    # from below the ephemeral range: a port handed out by bind(0) can become the source port of somebody's outgoing connection
+    # before the rendezvous listens on it (bench.py, _free_port)
+    import random
+
+    for _ in range(64):
+        p = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+            return p
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError("no free port")
 
 
 def _worker(rank, world, port, out_path, wire):
