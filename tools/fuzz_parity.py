@@ -71,6 +71,9 @@ def run(cases, seed, size, scenes=None, verbose=False, shortcut_heavy=False):
             if shortcut_heavy:  # the pixel schedule with step shortcuts on, eight lights in half of the cases: what the escape rules and the delivered shadow rays see
                 schedule = 1
                 f.extension_lights = limits["extension_lights"] = int(rng.choice([0, 7]))
+                if rng.random() < 0.5:  # any ray budget and queue length: the delivered shadow rays have to respect both
+                    f.bounce_count = limits["bounce_count"] = int(rng.integers(1, 17))
+                    f.ray_count = limits["ray_count"] = int(rng.integers(1, 9))
                 r.setLimits(**limits)
             r.setSchedule(schedule)
             r.setLaunchMode(int(rng.choice([sp.LAUNCH_AUTO, sp.LAUNCH_PER_TILE, sp.LAUNCH_PERSISTENT])))  # pixel schedule: how the tiles reach the waves
